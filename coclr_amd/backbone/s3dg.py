@@ -1,0 +1,213 @@
+"""S3D / S3D-G separable-3D-conv backbone on the gfx950 kernel engine.
+
+Same module tree, parameter/buffer names, init distributions and RNG
+consumption order as the reference backbone/s3dg.py (BasicConv3d :8-28,
+STConv3d :30-65, SelfGating :68-78, SepInception :81-132, S3D :135-217), so
+reference checkpoints load with strict=True -- including the alias keys that
+come from registering every stage both by name and inside `blockN`.
+
+The nn.Conv3d / nn.BatchNorm3d children are parameter containers only; their
+ATen forward is never called.  Each module implements `_emit(run, val)`, which
+enqueues HIP kernels through coclr_amd.engine; `forward` wraps a whole
+(sub)network in a single autograd node.
+"""
+import torch.nn as nn
+
+from .. import engine
+
+
+class _Emitter(nn.Module):
+    """nn.Module whose forward is an engine run over `_emit`."""
+
+    def forward(self, x, **kw):
+        return engine.run_module(self, x, **kw)
+
+
+def _conv_bn(cin, cout, kernel, stride, padding):
+    """(Conv3d, BatchNorm3d) initialised like s3dg.py:20-22 / :51-56."""
+    conv = nn.Conv3d(cin, cout, kernel_size=kernel, stride=stride, padding=padding, bias=False)
+    bn = nn.BatchNorm3d(cout)          # PyTorch defaults: eps 1e-5, momentum 0.1 (s3dg.py:5,16)
+    return conv, bn
+
+
+def _init_conv_bn(conv, bn):
+    conv.weight.data.normal_(mean=0, std=0.01)
+    bn.weight.data.fill_(1)
+    bn.bias.data.zero_()
+
+
+class BasicConv3d(_Emitter):
+    """conv(bias=False) -> BN -> ReLU."""
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride, padding=0):
+        super().__init__()
+        self.conv, self.bn = _conv_bn(in_planes, out_planes, kernel_size, stride, padding)
+        self.relu = nn.ReLU(inplace=True)
+        _init_conv_bn(self.conv, self.bn)
+
+    def _emit(self, run, x, out=None, n_index=None):
+        return engine.conv_bn_act(run, x, self.conv, self.bn, relu=True, out=out, n_index=n_index)
+
+
+class STConv3d(_Emitter):
+    """Separable conv: (1,k,k) spatial then (k,1,1) temporal, each with BN+ReLU.
+    A tuple stride means (t_stride, ..., spatial_stride) as in s3dg.py:33-37."""
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride, padding=0):
+        super().__init__()
+        if isinstance(stride, tuple):
+            t_stride, s_stride = stride[0], stride[-1]
+        else:
+            t_stride = s_stride = stride
+        self.conv1 = nn.Conv3d(in_planes, out_planes, kernel_size=(1, kernel_size, kernel_size),
+                               stride=(1, s_stride, s_stride), padding=(0, padding, padding),
+                               bias=False)
+        self.conv2 = nn.Conv3d(out_planes, out_planes, kernel_size=(kernel_size, 1, 1),
+                               stride=(t_stride, 1, 1), padding=(padding, 0, 0), bias=False)
+        self.bn1 = nn.BatchNorm3d(out_planes)
+        self.bn2 = nn.BatchNorm3d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+        # RNG order of the reference: conv1 weights, then conv2 weights
+        self.conv1.weight.data.normal_(mean=0, std=0.01)
+        self.conv2.weight.data.normal_(mean=0, std=0.01)
+        for bn in (self.bn1, self.bn2):
+            bn.weight.data.fill_(1)
+            bn.bias.data.zero_()
+
+    def _emit(self, run, x, out=None, n_index=None):
+        mid = engine.conv_bn_act(run, x, self.conv1, self.bn1, relu=True, n_index=n_index)
+        return engine.conv_bn_act(run, mid, self.conv2, self.bn2, relu=True, out=out)
+
+
+class SelfGating(_Emitter):
+    def __init__(self, input_dim):
+        super().__init__()
+        self.fc = nn.Linear(input_dim, input_dim)
+
+    def _emit(self, run, x, out=None):
+        return engine.self_gating(run, x, self.fc, out=out)
+
+
+class _Pool(nn.MaxPool3d):
+    """nn.MaxPool3d node of the layer program."""
+
+    def forward(self, x):
+        return engine.run_module(self, x)
+
+    def _emit(self, run, x):
+        return engine.max_pool(run, x, self.kernel_size, self.stride, self.padding)
+
+
+class _Chain(nn.Sequential):
+    """nn.Sequential whose members are emitted into the caller's run."""
+
+    def forward(self, x, **kw):
+        return engine.run_module(self, x, **kw)
+
+    def _emit(self, run, x, out=None, n_index=None):
+        mods = list(self)
+        for i, m in enumerate(mods):
+            kw = {}
+            if i == 0 and n_index is not None:
+                kw["n_index"] = n_index
+            if i == len(mods) - 1 and out is not None:
+                kw["out"] = out
+            x = m._emit(run, x, **kw)
+        return x
+
+
+class SepInception(_Emitter):
+    """Four-branch separable inception block; out_planes = [b0, b1a, b1b, b2a, b2b, b3b]
+    and the output channels are b0 | b1b | b2b | b3b in that order (s3dg.py:88-130)."""
+
+    def __init__(self, in_planes, out_planes, gating=False):
+        super().__init__()
+        assert isinstance(out_planes, list) and len(out_planes) == 6
+        b0, b1a, b1b, b2a, b2b, b3b = out_planes
+        self.branch0 = _Chain(BasicConv3d(in_planes, b0, kernel_size=1, stride=1))
+        self.branch1 = _Chain(BasicConv3d(in_planes, b1a, kernel_size=1, stride=1),
+                              STConv3d(b1a, b1b, kernel_size=3, stride=1, padding=1))
+        self.branch2 = _Chain(BasicConv3d(in_planes, b2a, kernel_size=1, stride=1),
+                              STConv3d(b2a, b2b, kernel_size=3, stride=1, padding=1))
+        self.branch3 = _Chain(_Pool(kernel_size=(3, 3, 3), stride=1, padding=1),
+                              BasicConv3d(in_planes, b3b, kernel_size=1, stride=1))
+        self._widths = (b0, b1b, b2b, b3b)
+        self.out_channels = sum(self._widths)
+        self.gating = gating
+        if gating:
+            self.gating_b0 = SelfGating(b0)
+            self.gating_b1 = SelfGating(b1b)
+            self.gating_b2 = SelfGating(b2b)
+            self.gating_b3 = SelfGating(b3b)
+
+    def _emit(self, run, x):
+        branches = (self.branch0, self.branch1, self.branch2, self.branch3)
+        N, _, T, H, W = x.shape
+        odim = (T, H, W)          # every branch preserves the extent
+        block = run.empty(N, self.out_channels, *odim)
+        c0 = 0
+        for i, (br, width) in enumerate(zip(branches, self._widths)):
+            dst = engine.Val(block, c0, width)
+            if self.gating:
+                y = br._emit(run, x)
+                getattr(self, "gating_b%d" % i)._emit(run, y, out=dst)
+            else:
+                br._emit(run, x, out=dst)
+            c0 += width
+        return engine.Val(block)
+
+
+# stage table: (attribute name, constructor) in registration order; `blockN`
+# aliases are built from these exactly like s3dg.py:147-192.
+_INCEPTION = {
+    "Mixed_3b": (192, [64, 96, 128, 16, 32, 32]),
+    "Mixed_3c": (256, [128, 128, 192, 32, 96, 64]),
+    "Mixed_4b": (480, [192, 96, 208, 16, 48, 64]),
+    "Mixed_4c": (512, [160, 112, 224, 24, 64, 64]),
+    "Mixed_4d": (512, [128, 128, 256, 24, 64, 64]),
+    "Mixed_4e": (512, [112, 144, 288, 32, 64, 64]),
+    "Mixed_4f": (528, [256, 160, 320, 32, 128, 128]),
+    "Mixed_5b": (832, [256, 160, 320, 32, 128, 128]),
+    "Mixed_5c": (832, [384, 192, 384, 48, 128, 128]),
+}
+
+
+class S3D(_Emitter):
+    def __init__(self, input_channel=3, gating=False, slow=False):
+        super().__init__()
+        self.gating = gating
+        self.slow = slow
+
+        stem_stride = (1, 2, 2) if slow else 2
+        self.Conv_1a = STConv3d(input_channel, 64, kernel_size=7, stride=stem_stride, padding=3)
+        self.block1 = _Chain(self.Conv_1a)
+
+        self.MaxPool_2a = _Pool(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self.Conv_2b = BasicConv3d(64, 64, kernel_size=1, stride=1)
+        self.Conv_2c = STConv3d(64, 192, kernel_size=3, stride=1, padding=1)
+        self.block2 = _Chain(self.MaxPool_2a, self.Conv_2b, self.Conv_2c)
+
+        self.MaxPool_3a = _Pool(kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self._add_inceptions("Mixed_3b", "Mixed_3c")
+        self.block3 = _Chain(self.MaxPool_3a, self.Mixed_3b, self.Mixed_3c)
+
+        self.MaxPool_4a = _Pool(kernel_size=(3, 3, 3), stride=(2, 2, 2), padding=(1, 1, 1))
+        self._add_inceptions("Mixed_4b", "Mixed_4c", "Mixed_4d", "Mixed_4e", "Mixed_4f")
+        self.block4 = _Chain(self.MaxPool_4a, self.Mixed_4b, self.Mixed_4c, self.Mixed_4d,
+                             self.Mixed_4e, self.Mixed_4f)
+
+        self.MaxPool_5a = _Pool(kernel_size=(2, 2, 2), stride=(2, 2, 2), padding=(0, 0, 0))
+        self._add_inceptions("Mixed_5b", "Mixed_5c")
+        self.block5 = _Chain(self.MaxPool_5a, self.Mixed_5b, self.Mixed_5c)
+
+    def _add_inceptions(self, *names):
+        for name in names:
+            cin, widths = _INCEPTION[name]
+            setattr(self, name, SepInception(in_planes=cin, out_planes=list(widths),
+                                             gating=self.gating))
+
+    def _emit(self, run, x, n_index=None):
+        x = self.block1._emit(run, x, n_index=n_index)
+        for blk in (self.block2, self.block3, self.block4, self.block5):
+            x = blk._emit(run, x)
+        return x

@@ -1,0 +1,346 @@
+// Train/eval BatchNorm3d (+ReLU, + optional residual add) around the conv
+// kernels, NCDHW fp32.  Replaces ATen batch_norm / relu_ / their backward as
+// invoked from backbone/s3dg.py:16-17,25-27,46-48,59-64 and
+// backbone/resnet_2d3d.py:54-83 (eps 1e-5, momentum 0.1 defaults).
+//
+// All of these are HBM-bound streaming kernels: 16 B/lane loads, one
+// (n, c) plane per blockIdx.y stripe, per-channel coefficients in SGPRs.
+// The batch statistics themselves come for free from the conv epilogue
+// (partial sums per workgroup); bn_finalize folds them in fp64.
+#include "common.h"
+#include "../../include/coclr_hip.h"
+
+namespace {
+
+// ---- forward -----------------------------------------------------------------
+
+// One block per channel: fold [2][C][ntiles] partial sums, emit mean / invstd /
+// fused scale+shift, update running stats (unbiased var), bump num_batches_tracked.
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float* __restrict__ stats, int C, int ntiles, double count,
+                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                   float momentum, float eps, float* mean_out, float* invstd_out,
+                   float* scale_out, float* shift_out) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  const float* ps = stats + (long)c * ntiles;
+  const float* pq = stats + ((long)C + c) * ntiles;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < ntiles; i += 256) { s += (double)ps[i]; q += (double)pq[i]; }
+  s = block256_sum_d(s, red);
+  q = block256_sum_d(q, red);
+  if (threadIdx.x == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    scale_out[c] = sc;
+    shift_out[c] = b - (float)mean * sc;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv,
+                                      float eps, int C, float* mean_out, float* invstd_out,
+                                      float* scale_out, float* shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * invstd;
+  mean_out[c] = rm[c];
+  invstd_out[c] = invstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - rm[c] * sc;
+}
+
+// z = act(y*scale[c] + shift[c] (+ res)),  act = ReLU or identity.
+// y is contiguous [N][C][S]; z/res may live inside wider tensors (channel
+// slices of a concat buffer) -> explicit sample strides.
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_act_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                    const float* __restrict__ shift, const float* __restrict__ res, float* z,
+                    int N, int C, int S, long z_nstride, long res_nstride, int relu) {
+  const int planes = N * C;
+  for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+    const int n = pl / C, c = pl - n * C;
+    const float sc = scale[c], sf = shift[c];
+    const float* yp = y + (long)pl * S;
+    float* zp = z + (long)n * z_nstride + (long)c * S;
+    const float* rp = res ? res + (long)n * res_nstride + (long)c * S : nullptr;
+    if (VEC) {
+      const int S4 = S >> 2;
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < S4; i += gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(yp)[i];
+        v.x = fmaf(v.x, sc, sf); v.y = fmaf(v.y, sc, sf);
+        v.z = fmaf(v.z, sc, sf); v.w = fmaf(v.w, sc, sf);
+        if (rp) {
+          const float4 r = reinterpret_cast<const float4*>(rp)[i];
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        reinterpret_cast<float4*>(zp)[i] = v;
+      }
+    } else {
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
+        float v = fmaf(yp[i], sc, sf);
+        if (rp) v += rp[i];
+        if (relu) v = fmaxf(v, 0.f);
+        zp[i] = v;
+      }
+    }
+  }
+}
+
+// ---- backward ----------------------------------------------------------------
+
+// sums[c] += (sum g, sum g*xhat), g = dz * mask.  mask = (z > 0) when z is given
+// (residual units), else recomputed as (y*scale+shift > 0); no mask if !relu.
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_act_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                         const float* __restrict__ z, const float* __restrict__ scale,
+                         const float* __restrict__ shift, const float* __restrict__ mean,
+                         const float* __restrict__ invstd, double* sums, int N, int C, int S,
+                         long dz_nstride, long z_nstride, int relu) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  const float sc = scale[c], sf = shift[c], mu = mean[c], is = invstd[c];
+  double sg = 0.0, sgx = 0.0;
+  for (int n = blockIdx.y; n < N; n += gridDim.y) {
+    const float* dzp = dz + (long)n * dz_nstride + (long)c * S;
+    const float* yp = y + ((long)n * C + c) * S;
+    const float* zp = z ? z + (long)n * z_nstride + (long)c * S : nullptr;
+    float ag = 0.f, agx = 0.f;
+    if (VEC) {
+      const int S4 = S >> 2;
+      for (int i = threadIdx.x; i < S4; i += 256) {
+        const float4 d = reinterpret_cast<const float4*>(dzp)[i];
+        const float4 v = reinterpret_cast<const float4*>(yp)[i];
+        float g0 = d.x, g1 = d.y, g2 = d.z, g3 = d.w;
+        if (relu) {
+          if (zp) {
+            const float4 zz = reinterpret_cast<const float4*>(zp)[i];
+            g0 = zz.x > 0.f ? g0 : 0.f; g1 = zz.y > 0.f ? g1 : 0.f;
+            g2 = zz.z > 0.f ? g2 : 0.f; g3 = zz.w > 0.f ? g3 : 0.f;
+          } else {
+            g0 = fmaf(v.x, sc, sf) > 0.f ? g0 : 0.f; g1 = fmaf(v.y, sc, sf) > 0.f ? g1 : 0.f;
+            g2 = fmaf(v.z, sc, sf) > 0.f ? g2 : 0.f; g3 = fmaf(v.w, sc, sf) > 0.f ? g3 : 0.f;
+          }
+        }
+        ag += (g0 + g1) + (g2 + g3);
+        agx += g0 * ((v.x - mu) * is) + g1 * ((v.y - mu) * is) + g2 * ((v.z - mu) * is) +
+               g3 * ((v.w - mu) * is);
+      }
+    } else {
+      for (int i = threadIdx.x; i < S; i += 256) {
+        float g = dzp[i];
+        const float v = yp[i];
+        if (relu) g = (zp ? zp[i] > 0.f : fmaf(v, sc, sf) > 0.f) ? g : 0.f;
+        ag += g;
+        agx += g * ((v - mu) * is);
+      }
+    }
+    sg += (double)ag;
+    sgx += (double)agx;
+  }
+  sg = block256_sum_d(sg, red);
+  sgx = block256_sum_d(sgx, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[2 * c], sg);
+    atomicAdd(&sums[2 * c + 1], sgx);
+  }
+}
+
+// Per-channel coefficients for the apply pass and the parameter gradients.
+//   training: dy = A*g + Bc*y + D  with  A = scale, Bc = -scale*invstd*mgx,
+//             D = scale*(mean*invstd*mgx - mg);  eval: dy = scale*g.
+__global__ void bn_bwd_coeff_kernel(const double* __restrict__ sums, const float* __restrict__ scale,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    double count, int C, int training, float* coefA, float* coefB,
+                                    float* coefD, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = sums[2 * c], sgx = sums[2 * c + 1];
+  if (dgamma) dgamma[c] = (float)sgx;
+  if (dbeta) dbeta[c] = (float)sg;
+  const float s = scale[c];
+  if (training) {
+    const float mg = (float)(sg / count), mgx = (float)(sgx / count);
+    coefA[c] = s;
+    coefB[c] = -s * invstd[c] * mgx;
+    coefD[c] = s * (mean[c] * invstd[c] * mgx - mg);
+  } else {
+    coefA[c] = s; coefB[c] = 0.f; coefD[c] = 0.f;
+  }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                        const float* __restrict__ z, const float* __restrict__ scale,
+                        const float* __restrict__ shift, const float* __restrict__ coefA,
+                        const float* __restrict__ coefB, const float* __restrict__ coefD, float* dy,
+                        float* dres, int N, int C, int S, long dz_nstride, long z_nstride,
+                        long dres_nstride, int relu, int dres_accumulate) {
+  const int planes = N * C;
+  for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+    const int n = pl / C, c = pl - n * C;
+    const float sc = scale[c], sf = shift[c];
+    const float A = coefA[c], B = coefB[c], D = coefD[c];
+    const float* dzp = dz + (long)n * dz_nstride + (long)c * S;
+    const float* yp = y + (long)pl * S;
+    const float* zp = z ? z + (long)n * z_nstride + (long)c * S : nullptr;
+    float* dyp = dy + (long)pl * S;
+    float* drp = dres ? dres + (long)n * dres_nstride + (long)c * S : nullptr;
+    if (VEC) {
+      const int S4 = S >> 2;
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < S4; i += gridDim.x * 256) {
+        const float4 d = reinterpret_cast<const float4*>(dzp)[i];
+        const float4 v = reinterpret_cast<const float4*>(yp)[i];
+        float4 g = d;
+        if (relu) {
+          if (zp) {
+            const float4 zz = reinterpret_cast<const float4*>(zp)[i];
+            g.x = zz.x > 0.f ? g.x : 0.f; g.y = zz.y > 0.f ? g.y : 0.f;
+            g.z = zz.z > 0.f ? g.z : 0.f; g.w = zz.w > 0.f ? g.w : 0.f;
+          } else {
+            g.x = fmaf(v.x, sc, sf) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, sc, sf) > 0.f ? g.y : 0.f;
+            g.z = fmaf(v.z, sc, sf) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, sc, sf) > 0.f ? g.w : 0.f;
+          }
+        }
+        if (drp) {
+          float4 r = g;
+          if (dres_accumulate) {
+            const float4 o = reinterpret_cast<const float4*>(drp)[i];
+            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+          }
+          reinterpret_cast<float4*>(drp)[i] = r;
+        }
+        float4 o;
+        o.x = fmaf(A, g.x, fmaf(B, v.x, D)); o.y = fmaf(A, g.y, fmaf(B, v.y, D));
+        o.z = fmaf(A, g.z, fmaf(B, v.z, D)); o.w = fmaf(A, g.w, fmaf(B, v.w, D));
+        reinterpret_cast<float4*>(dyp)[i] = o;
+      }
+    } else {
+      for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
+        float g = dzp[i];
+        const float v = yp[i];
+        if (relu) g = (zp ? zp[i] > 0.f : fmaf(v, sc, sf) > 0.f) ? g : 0.f;
+        if (drp) drp[i] = dres_accumulate ? drp[i] + g : g;
+        dyp[i] = fmaf(A, g, fmaf(B, v, D));
+      }
+    }
+  }
+}
+
+inline dim3 plane_grid(int planes, int S) {
+  int gx = cdiv(S >> 2 ? S >> 2 : S, 256 * 4);
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  int gy = planes;
+  const int cap = 65535;
+  if (gy > cap) gy = cap;
+  // keep total blocks bounded for very large tensors
+  while ((long)gx * gy > 262144 && gx > 1) gx >>= 1;
+  return dim3(gx, gy);
+}
+
+}  // namespace
+
+extern "C" int coclr_bn_finalize(const float* stats, int C, int ntiles, double count,
+                                 const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, int64_t* num_batches_tracked, float momentum,
+                                 float eps, float* mean, float* invstd, float* scale, float* shift,
+                                 void* stream) {
+  if (C <= 0 || ntiles <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, C,
+                     ntiles, count, gamma, beta, running_mean, running_var, num_batches_tracked,
+                     momentum, eps, mean, invstd, scale, shift);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, int C, float* mean,
+                                    float* invstd, float* scale, float* shift, void* stream) {
+  if (C <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     gamma, beta, running_mean, running_var, eps, C, mean, invstd, scale, shift);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_bn_act_apply(const float* y, const float* scale, const float* shift,
+                                  const float* residual, float* z, int N, int C, int64_t S,
+                                  int64_t z_nstride, int64_t res_nstride, int relu, void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return COCLR_EINVAL;
+  const bool vec = (S % 4 == 0) && (z_nstride % 4 == 0) && (!residual || res_nstride % 4 == 0);
+  dim3 grid = plane_grid(N * C, (int)S);
+  if (vec)
+    hipLaunchKernelGGL(bn_act_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, scale,
+                       shift, residual, z, N, C, (int)S, (long)z_nstride, (long)res_nstride, relu);
+  else
+    hipLaunchKernelGGL(bn_act_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, scale,
+                       shift, residual, z, N, C, (int)S, (long)z_nstride, (long)res_nstride, relu);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const float* z,
+                                     const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, double* sums_ws, float* coef_ws, float* dy,
+                                     float* dres, float* dgamma, float* dbeta, int N, int C,
+                                     int64_t S, int64_t dz_nstride, int64_t z_nstride,
+                                     int64_t dres_nstride, int relu, int training,
+                                     int dres_accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N <= 0 || C <= 0 || S <= 0) return COCLR_EINVAL;
+  const bool vec = (S % 4 == 0) && (dz_nstride % 4 == 0) && (!z || z_nstride % 4 == 0) &&
+                   (!dres || dres_nstride % 4 == 0);
+  COCLR_RETURN_IF(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, stream));
+  int gy = N;
+  // more split for tiny batches of huge planes is not needed: planes are big then
+  dim3 rgrid(C, gy);
+  if (vec)
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, stream, dz, y, z, scale,
+                       shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride,
+                       (long)z_nstride, relu);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, stream, dz, y, z,
+                       scale, shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride,
+                       (long)z_nstride, relu);
+  COCLR_LAUNCH_CHECK();
+  float* coefA = coef_ws;
+  float* coefB = coef_ws + C;
+  float* coefD = coef_ws + 2 * C;
+  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums_ws, scale,
+                     mean, invstd, (double)N * (double)S, C, training, coefA, coefB, coefD, dgamma,
+                     dbeta);
+  COCLR_LAUNCH_CHECK();
+  dim3 grid = plane_grid(N * C, (int)S);
+  if (vec)
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, grid, dim3(256), 0, stream, dz, y, z, scale,
+                       shift, coefA, coefB, coefD, dy, dres, N, C, (int)S, (long)dz_nstride,
+                       (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, grid, dim3(256), 0, stream, dz, y, z, scale,
+                       shift, coefA, coefB, coefD, dy, dres, N, C, (int)S, (long)dz_nstride,
+                       (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}

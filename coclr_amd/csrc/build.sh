@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libcoclr_hip.so for gfx950 in-tree (no GPU needed: hipcc cross-compiles).
+set -e
+cd "$(dirname "$0")"
+OUT=../libcoclr_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
+mkdir -p build
+pids=()
+for f in conv_igemm conv_wgrad bn pool nce version; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || \
+     [ conv_geom.h -nt build/$f.o ] || [ ../../include/coclr_hip.h -nt build/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
+echo "built $(realpath $OUT)"

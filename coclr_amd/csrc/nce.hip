@@ -1,0 +1,473 @@
+// MoCo / InfoNCE / CoCLR head kernels for gfx950 (model/pretrain.py):
+//   * skinny fp32-MFMA GEMM with arbitrary operand strides, split-K and a fused
+//     epilogue: the q . queue^T contraction (pretrain.py:176), its backward, the
+//     CoCLR cross-modal similarity (pretrain.py:405) and the 1x1x1 projection
+//     convs on pooled features (pretrain.py:52,54)
+//   * L2 normalise fwd/bwd (pretrain.py:154,167,380), l_pos (pretrain.py:175)
+//   * multi-tensor momentum update (pretrain.py:76-80)
+//   * FIFO queue enqueue with a device-resident pointer (pretrain.py:82-96,321-341)
+//   * per-row top-k mining + positive-mask build (pretrain.py:397-413, 267-269)
+//   * row gather for shuffle-BN (pretrain.py:124,143), ReLU, column sums
+#include "common.h"
+#include "../../include/coclr_hip.h"
+#include <math.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// C[m][n] (+)= act(alpha * sum_k A(m,k) B(k,n) + bias[n])
+// A(m,k) at a[m*sam + k*sak], B(k,n) at b[k*sbk + n*sbn].
+// TA: A is m-contiguous (sam == 1) else k-contiguous; TB: B is k-contiguous
+// (sbk == 1) else n-contiguous.  Tile 32 x 128 x 32, 4 waves, one
+// v_mfma_f32_32x32x2_f32 column block per wave.
+// ---------------------------------------------------------------------------
+struct GemmArgs {
+  const float* a; const float* b; float* c; const float* bias;
+  long sam, sak, sbk, sbn, ldc;
+  int M, N, K, kslice;
+  float alpha;
+  int relu, accumulate, splits;
+  float* part;   // [splits][M][N] when splits > 1
+};
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256)
+gemm32x128_kernel(const GemmArgs g) {
+  constexpr int BK = 32, LDA = 33, LDB = 129;
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 32;
+  const int split = blockIdx.z;
+  const int kbeg = split * g.kslice;
+  int kend = kbeg + g.kslice;
+  if (kend > g.K) kend = g.K;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      int m, k;
+      if (TA) { m = e & 31; k = e >> 5; } else { k = e & 31; m = e >> 5; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k * LDA + m] = (gm < g.M && gk < kend) ? g.a[gm * g.sam + gk * g.sak] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + i * 256;
+      int n, k;
+      if (TB) { k = e & 31; n = e >> 5; } else { n = e & 127; k = e >> 7; }
+      const int gn = n0 + n, gk = k0 + k;
+      Bs[k * LDB + n] = (gn < g.N && gk < kend) ? g.b[gk * g.sbk + gn * g.sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      const int k = 2 * s + half;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * LDA + l31], Bs[k * LDB + wave * 32 + l31],
+                                                 acc, 0, 0, 0);
+    }
+  }
+
+  const int gn = n0 + wave * 32 + l31;
+  if (gn >= g.N) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int gm = m0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+    if (gm >= g.M) continue;
+    if (g.splits > 1) {
+      g.part[((long)split * g.M + gm) * g.N + gn] = acc[i];
+    } else {
+      float v = acc[i] * g.alpha;
+      if (g.bias) v += g.bias[gn];
+      if (g.relu) v = fmaxf(v, 0.f);
+      float* d = g.c + gm * g.ldc + gn;
+      *d = g.accumulate ? *d + v : v;
+    }
+  }
+}
+
+__global__ void gemm_splitk_reduce_kernel(const GemmArgs g) {
+  const long MN = (long)g.M * g.N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < MN;
+       e += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < g.splits; ++k) s += g.part[(long)k * MN + e];
+    const long m = e / g.N;
+    const int n = (int)(e - m * g.N);
+    float v = s * g.alpha;
+    if (g.bias) v += g.bias[n];
+    if (g.relu) v = fmaxf(v, 0.f);
+    float* d = g.c + m * g.ldc + n;
+    *d = g.accumulate ? *d + v : v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// rows of length D: y = x / max(||x||, eps); one wave per row
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv_norm,
+                  int rows, int D, float eps) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xp = x + (long)row * D;
+  float ss = 0.f;
+  for (int i = lane; i < D; i += 64) ss += xp[i] * xp[i];
+  ss = wave_sum(ss);
+  const float inv = 1.f / fmaxf(sqrtf(ss), eps);
+  for (int i = lane; i < D; i += 64) y[(long)row * D + i] = xp[i] * inv;
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+}
+
+// dx = (dy - y * <y, dy>) * inv_norm
+__global__ void __launch_bounds__(256)
+l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                  const float* __restrict__ inv_norm, float* __restrict__ dx, int rows, int D) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* dyp = dy + (long)row * D;
+  const float* yp = y + (long)row * D;
+  float dot = 0.f;
+  for (int i = lane; i < D; i += 64) dot += dyp[i] * yp[i];
+  dot = wave_sum(dot);
+  const float inv = inv_norm[row];
+  for (int i = lane; i < D; i += 64) dx[(long)row * D + i] = (dyp[i] - yp[i] * dot) * inv;
+}
+
+// logits[b][0] = <q_b, k_b> * inv_T
+__global__ void __launch_bounds__(256)
+lpos_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, float* logits, int rows,
+                int D, long ldl, float inv_T) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += q[(long)row * D + i] * k[(long)row * D + i];
+  s = wave_sum(s);
+  if (lane == 0) logits[row * ldl] = s * inv_T;
+}
+
+// dq[b][:] += dlogits[b][0] * inv_T * k[b][:]
+__global__ void lpos_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ k,
+                                float* dq, int rows, int D, long ldl, float inv_T) {
+  const long total = (long)rows * D;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const long b = e / D;
+    dq[e] += dlogits[b * ldl] * inv_T * k[e];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// multi-tensor momentum update: table[3*i..] = {dst ptr, src ptr, count}
+// dst = dst*m + src*(1-m), rounded as two products and one add (matches the
+// reference's p_k*m + p_q*(1-m) tensor expression, no FMA contraction).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+momentum_update_kernel(const int64_t* __restrict__ table, float m, float one_minus_m) {
+  const int64_t* ent = table + 3 * (long)blockIdx.x;
+  float* dst = reinterpret_cast<float*>(ent[0]);
+  const float* src = reinterpret_cast<const float*>(ent[1]);
+  const int cnt = (int)ent[2];
+  for (int i = threadIdx.x; i < cnt; i += 256)
+    dst[i] = __fadd_rn(__fmul_rn(dst[i], m), __fmul_rn(src[i], one_minus_m));
+}
+
+// ---------------------------------------------------------------------------
+// queue[:, ptr:ptr+BW] = keys^T   (queue is [D][K], keys is [BW][D])
+// ---------------------------------------------------------------------------
+__global__ void queue_enqueue_kernel(float* queue, const float* __restrict__ keys, int D, int K,
+                                     int BW, const int64_t* __restrict__ ptr) {
+  const int p = (int)(*ptr);
+  const int total = D * BW;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int d = e / BW, j = e - d * BW;   // j fastest: contiguous writes along a queue row
+    queue[(long)d * K + p + j] = keys[(long)j * D + d];
+  }
+}
+
+__global__ void queue_fill_i64_kernel(int64_t* q, const int64_t* __restrict__ vals, int64_t cval,
+                                      int BW, const int64_t* __restrict__ ptr) {
+  const int p = (int)(*ptr);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < BW; j += gridDim.x * blockDim.x)
+    q[p + j] = vals ? vals[j] : cval;
+}
+
+__global__ void queue_advance_kernel(int64_t* ptr, int BW, int K) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *ptr = (*ptr + BW) % K;
+}
+
+// ---------------------------------------------------------------------------
+// mask[b][0] = 1; mask[b][1+j] = (src[b] == names[j]) | (j in top-k of sim[b] with
+// the same-source entries excluded).  One block per row, row cached in LDS.
+// Ties resolve to the lowest column (torch.topk leaves tie order unspecified).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+positive_mask_kernel(const float* __restrict__ sim, const int64_t* __restrict__ src,
+                     const int64_t* __restrict__ names, uint8_t* __restrict__ mask, int K,
+                     int topk) {
+  extern __shared__ float row[];   // K floats
+  __shared__ float wbest[4];
+  __shared__ int widx[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t s = src[b];
+  uint8_t* mrow = mask + (long)b * (1 + K);
+  if (tid == 0) mrow[0] = 1;
+  for (int j = tid; j < K; j += 256) {
+    const bool same = names[j] == s;
+    mrow[1 + j] = same ? 1 : 0;
+    if (topk > 0) row[j] = same ? -INFINITY : sim[(long)b * K + j];
+  }
+  for (int t = 0; t < topk; ++t) {
+    __syncthreads();
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < K; j += 256) {
+      const float v = row[j];
+      // NaN-free inputs assumed (unit vectors); prefer lower index on ties
+      if (v > best || (v == best && j < bi)) { best = v; bi = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bi, off);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((tid & 63) == 0) { wbest[tid >> 6] = best; widx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (wbest[w] > best || (wbest[w] == best && widx[w] < bi)) { best = wbest[w]; bi = widx[w]; }
+      if (bi < K) {
+        mrow[1 + bi] = 1;
+        // NaN marks "already taken": never compares greater, unlike -inf which
+        // must stay selectable when fewer than topk finite candidates remain
+        row[bi] = __builtin_nanf("");
+      }
+    }
+  }
+}
+
+// out[i][:] = in[idx[i]][:]   (rows of `row_elems` floats)
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, float* out,
+                   long row_elems) {
+  const long r = blockIdx.y;
+  const float* src = in + idx[r] * row_elems;
+  float* dst = out + r * row_elems;
+  if ((row_elems & 3) == 0) {
+    const long n4 = row_elems >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+      reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_elems; i += (long)gridDim.x * 256)
+      dst[i] = src[i];
+  }
+}
+
+__global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    y[e] = fmaxf(x[e], 0.f);
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                float* __restrict__ dx, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    dx[e] = y[e] > 0.f ? dy[e] : 0.f;
+}
+
+// out[c] = sum_r x[r][c]
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
+                              int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += x[(long)r * cols + c];
+  out[c] = s;
+}
+
+inline int grid1d(long n, int cap = 2048) {
+  long b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int coclr_gemm_workspace(int M, int N, int K, int splits, int64_t* elems) {
+  *elems = splits > 1 ? (int64_t)splits * M * N : 0;
+  return 0;
+}
+
+extern "C" int coclr_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk,
+                          int64_t sbn, float* c, int64_t ldc, const float* bias, int M, int N,
+                          int K, float alpha, int relu, int accumulate, int splits,
+                          float* workspace, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M <= 0 || N <= 0 || K <= 0 || splits < 1) return COCLR_EINVAL;
+  if (splits > 1 && !workspace) return COCLR_EINVAL;
+  GemmArgs g;
+  g.a = a; g.b = b; g.c = c; g.bias = bias;
+  g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K;
+  int kslice = cdiv(K, splits);
+  kslice = cdiv(kslice, 32) * 32;
+  g.kslice = kslice;
+  splits = cdiv(K, kslice);
+  g.splits = splits;
+  g.alpha = alpha; g.relu = relu; g.accumulate = accumulate; g.part = workspace;
+  dim3 grid(cdiv(N, 128), cdiv(M, 32), splits);
+  const bool TA = (sam == 1 && sak != 1), TB = (sbk == 1 && sbn != 1);
+  if (TA && TB) hipLaunchKernelGGL((gemm32x128_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  else if (TA) hipLaunchKernelGGL((gemm32x128_kernel<true, false>), grid, dim3(256), 0, stream, g);
+  else if (TB) hipLaunchKernelGGL((gemm32x128_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm32x128_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  COCLR_LAUNCH_CHECK();
+  if (splits > 1) {
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(grid1d((long)M * N)), dim3(256), 0, stream, g);
+    COCLR_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int coclr_l2norm_fwd(const float* x, float* y, float* inv_norm, int rows, int D,
+                                float eps, void* stream) {
+  if (rows <= 0 || D <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv((long)rows * 64, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, inv_norm, rows, D, eps);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx,
+                                int rows, int D, void* stream) {
+  if (rows <= 0 || D <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv((long)rows * 64, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, y, inv_norm, dx, rows, D);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+// logits[B][1+K] = [ <q,k> | q . queue ] / T      (model/pretrain.py:175-182)
+extern "C" int coclr_nce_logits_fwd(const float* q, const float* k, const float* queue,
+                                    float* logits, int B, int D, int K, float T, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || D <= 0 || K <= 0 || T == 0.f) return COCLR_EINVAL;
+  const float inv_T = 1.f / T;
+  hipLaunchKernelGGL(lpos_fwd_kernel, dim3(cdiv((long)B * 64, 256)), dim3(256), 0, stream, q, k,
+                     logits, B, D, (long)(1 + K), inv_T);
+  COCLR_LAUNCH_CHECK();
+  return coclr_gemm(q, D, 1, queue, K, 1, logits + 1, 1 + K, nullptr, B, K, D, inv_T, 0, 0, 1,
+                    nullptr, stream_);
+}
+
+// dq[B][D] = ( dlogits[:,1:] . queue^T + dlogits[:,0] * k ) / T
+extern "C" int coclr_nce_logits_bwd(const float* dlogits, const float* k, const float* queue,
+                                    float* dq, float* workspace, int B, int D, int K, float T,
+                                    int splits, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || D <= 0 || K <= 0 || T == 0.f) return COCLR_EINVAL;
+  const float inv_T = 1.f / T;
+  // A(m,k') = dlogits[m][1+k'] (k' contiguous), B(k',n) = queue[n][k'] (k' contiguous)
+  int rc = coclr_gemm(dlogits + 1, 1 + K, 1, queue, 1, K, dq, D, nullptr, B, D, K, inv_T, 0, 0,
+                      splits, workspace, stream_);
+  if (rc) return rc;
+  hipLaunchKernelGGL(lpos_bwd_kernel, dim3(grid1d((long)B * D)), dim3(256), 0, stream, dlogits, k,
+                     dq, B, D, (long)(1 + K), inv_T);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_momentum_update(const int64_t* table, int nchunks, float m, float one_minus_m,
+                                     void* stream) {
+  if (nchunks <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(momentum_update_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                     table, m, one_minus_m);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_queue_enqueue(float* queue, const float* keys, int D, int K, int BW,
+                                   const int64_t* ptr, void* stream) {
+  if (D <= 0 || K <= 0 || BW <= 0 || BW > K || K % BW != 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(queue_enqueue_kernel, dim3(grid1d((long)D * BW)), dim3(256), 0,
+                     (hipStream_t)stream, queue, keys, D, K, BW, ptr);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_queue_fill_i64(int64_t* queue, const int64_t* vals, int64_t const_val, int K,
+                                    int BW, const int64_t* ptr, void* stream) {
+  if (K <= 0 || BW <= 0 || BW > K) return COCLR_EINVAL;
+  hipLaunchKernelGGL(queue_fill_i64_kernel, dim3(grid1d(BW)), dim3(256), 0, (hipStream_t)stream,
+                     queue, vals, const_val, BW, ptr);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_queue_advance(int64_t* ptr, int BW, int K, void* stream) {
+  if (K <= 0 || BW <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(queue_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ptr, BW, K);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_positive_mask(const float* sim, const int64_t* src, const int64_t* names,
+                                   uint8_t* mask, int B, int K, int topk, void* stream) {
+  if (B <= 0 || K <= 0 || topk < 0 || topk > K) return COCLR_EINVAL;
+  if (topk > 0 && !sim) return COCLR_EINVAL;
+  const size_t lds = topk > 0 ? (size_t)K * sizeof(float) : 0;
+  if (lds > 150 * 1024) return COCLR_EINVAL;
+  static bool attr_done = false;
+  if (!attr_done) {
+    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(positive_mask_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(positive_mask_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sim, src,
+                     names, mask, K, topk);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_gather_rows(const float* in, const int64_t* idx, float* out, int rows,
+                                 int64_t row_elems, void* stream) {
+  if (rows <= 0 || row_elems <= 0) return COCLR_EINVAL;
+  int gx = (int)((row_elems / 4 + 255) / 256);
+  if (gx < 1) gx = 1;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, in, idx,
+                     out, (long)row_elems);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_relu_fwd(const float* x, float* y, int64_t n, void* stream) {
+  if (n <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(relu_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     (long)n);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+  if (n <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx,
+                     (long)n);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_colsum(const float* x, float* out, int rows, int cols, void* stream) {
+  if (rows <= 0 || cols <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, x, out,
+                     rows, cols);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}

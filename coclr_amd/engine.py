@@ -1,0 +1,347 @@
+"""Layer-program executor for the conv backbones.
+
+The reference lets ATen's autograd record ~255 tiny ops per encoder pass
+(backbone/s3dg.py:211-217).  Here a backbone forward is one *run*: modules emit
+kernel launches through this executor, which keeps its own reverse tape of
+closures.  A single torch.autograd.Function (`EngineFn`) wraps the whole run,
+so autograd / DDP only ever see "backbone(x, *params) -> feature map" and
+receive all parameter gradients when the tape has been replayed.
+
+What that buys on MI355X:
+  * branches of an inception block write straight into channel slices of the
+    block output (no torch.cat), gradients are read back from slices
+  * conv -> BN statistics are produced by the conv epilogue, BN+ReLU is one
+    streaming pass, its backward one reduce + one apply pass
+  * data gradients of fan-out nodes accumulate in place (accumulate flag on the
+    kernel) instead of separate add kernels
+  * the launch sequence is static per input shape (hipGraph-capturable)
+"""
+import torch
+
+from . import ops
+
+
+class Val:
+    """An activation: channels [c0, c0+C) of the dense NCDHW tensor `base`."""
+    __slots__ = ("base", "c0", "C")
+
+    def __init__(self, base, c0=0, C=None):
+        self.base = base
+        self.c0 = c0
+        self.C = base.shape[1] - c0 if C is None else C
+
+    @property
+    def whole(self):
+        return self.c0 == 0 and self.C == self.base.shape[1]
+
+    def view(self):
+        return self.base if self.whole else self.base[:, self.c0:self.c0 + self.C]
+
+    @property
+    def shape(self):
+        b = self.base.shape
+        return (b[0], self.C, b[2], b[3], b[4])
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+class Run:
+    """One forward pass (and, if `save`, the tape to differentiate it)."""
+
+    def __init__(self, device, save, need_input_grad=False):
+        self.device = device
+        self.save = save
+        self.need_input_grad = need_input_grad
+        self.tape = []
+        self.grads = {}        # id(base tensor) -> grad tensor
+        self.param_grads = {}  # id(param) -> grad tensor
+        self.no_grad_bases = set()
+        self.out = None
+
+    # -- allocation helpers ------------------------------------------------------
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def needs_grad(self, val):
+        return self.save and id(val.base) not in self.no_grad_bases
+
+    def grad_target(self, val):
+        """(tensor to write d(val) into, accumulate?)"""
+        if not val.whole:
+            raise RuntimeError("coclr_amd: gradient into a channel slice is not supported")
+        g = self.grads.get(id(val.base))
+        if g is None:
+            g = torch.empty_like(val.base)
+            self.grads[id(val.base)] = g
+            return g, False
+        return g, True
+
+    def grad_of(self, val):
+        g = self.grads.get(id(val.base))
+        if g is None:
+            raise RuntimeError("coclr_amd: activation has no gradient (unused output?)")
+        return g if val.whole else g[:, val.c0:val.c0 + val.C]
+
+    def add_param_grad(self, p, g):
+        old = self.param_grads.get(id(p))
+        self.param_grads[id(p)] = g if old is None else old.add_(g)
+
+    # -- backward ----------------------------------------------------------------
+    def backward(self, dout):
+        out = self.out
+        self.grads[id(out.base)] = dout.contiguous()
+        while self.tape:
+            self.tape.pop()()
+        return self.grads
+
+    # -- weight packing ------------------------------------------------------------
+    def pack(self, w, transpose, kt_slice=None):
+        """[Cout][Cin][taps] -> [taps][Cin'][Cout'] (or the dgrad operand)."""
+        cout, cin, kt, kh, kw = w.shape
+        if kt_slice is None:
+            taps, base = kt * kh * kw, 0
+        else:
+            taps, base = kh * kw, kt_slice * kh * kw
+        n = ops.conv_packed_size(cin, cout, taps, transpose)
+        packed = self.empty(n)
+        ops.conv_pack_weights(w, packed, cout, cin, taps, cin * kt * kh * kw, kt * kh * kw, base,
+                              transpose)
+        return packed
+
+
+# ---------------------------------------------------------------------------------
+# conv (+ BatchNorm) (+ residual) (+ ReLU)
+# ---------------------------------------------------------------------------------
+
+def _is_plain_pointwise(k, s):
+    return k == (1, 1, 1) and s != (1, 1, 1)
+
+
+def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=None):
+    """One conv unit of the backbone.
+
+    x: Val.  conv: nn.Conv3d (bias-free) holding the weight.  bn: nn.BatchNorm3d.
+    out: optional Val (channel slice of a concat buffer) to receive the activation.
+    residual: optional Val added before the ReLU (ResNet bottleneck tail).
+    n_index: optional int64 tensor -- sample n of the conv input is x[n_index[n]].
+    Mirrors BasicConv3d.forward / the halves of STConv3d.forward
+    (backbone/s3dg.py:24-28,58-65) and the conv/bn/relu triplets of
+    backbone/resnet_2d3d.py:67-86.
+    """
+    w = conv.weight
+    k = tuple(w.shape[2:])
+    s, p = _triple(conv.stride), _triple(conv.padding)
+    if conv.bias is not None or _triple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
+        raise NotImplementedError("coclr_amd: backbone convs are bias-free, dense, undilated")
+    if _is_plain_pointwise(k, s):
+        # strided 1x1x1 (ResNet downsample): subsample first, then a dense pointwise conv
+        x = subsample(run, x, s)
+        s = (1, 1, 1)
+    N = n_index.shape[0] if n_index is not None else x.shape[0]
+    Cin, idim = x.shape[1], x.shape[2:]
+    Cout = w.shape[0]
+    if w.shape[1] != Cin:
+        raise ValueError("coclr_amd: conv expects %d input channels, got %d" % (w.shape[1], Cin))
+    xv = x.view()
+    training = bn.training or (bn.running_mean is None)
+
+    sliced = k[0] > 3 and k[1] > 1          # (5,7,7) stem: one launch per temporal tap
+    if sliced:
+        geoms = [ops.ConvGeom(N, Cin, Cout, idim, (1, k[1], k[2]), s, (p[0] - t, p[1], p[2]),
+                              odim=ops.ConvGeom(N, Cin, Cout, idim, k, s, p).odim)
+                 for t in range(k[0])]
+    else:
+        geoms = [ops.ConvGeom(N, Cin, Cout, idim, k, s, p)]
+    odim = geoms[0].odim
+    want_y = training or run.save or residual is not None
+
+    small = run.empty(4, Cout)       # mean, invstd, scale, shift
+    mean, invstd, scale, shift = small[0], small[1], small[2], small[3]
+    if out is None:
+        out = Val(run.empty(N, Cout, *odim))
+    zv = out.view()
+    y = None
+    if want_y:
+        y = run.empty(N, Cout, *odim)
+        stats = None
+        for t, g in enumerate(geoms):
+            last = t == len(geoms) - 1
+            if training and last:
+                stats = run.empty(2 * Cout * g.ntiles())
+            ops.conv_fwd(g, xv, run.pack(w, False, t if sliced else None), y,
+                         stats=stats if last else None, n_index=n_index, accumulate=t > 0)
+        if training:
+            if bn.momentum is None:
+                raise NotImplementedError("coclr_amd: cumulative-average BatchNorm momentum")
+            ops.bn_finalize(stats, Cout, geoms[-1].ntiles(), N * odim[0] * odim[1] * odim[2],
+                            bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            bn.num_batches_tracked, float(bn.momentum), float(bn.eps), mean,
+                            invstd, scale, shift)
+        else:
+            ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                               Cout, mean, invstd, scale, shift)
+        ops.bn_act_apply(y, scale, shift, residual.view() if residual is not None else None, zv,
+                         relu)
+    else:
+        # inference with frozen statistics: fold BN+ReLU into the conv epilogue
+        ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                           Cout, mean, invstd, scale, shift)
+        for t, g in enumerate(geoms):
+            last = t == len(geoms) - 1
+            ops.conv_fwd(g, xv, run.pack(w, False, t if sliced else None), zv,
+                         ep_scale=scale if last else None, ep_shift=shift if last else None,
+                         relu=relu and last, n_index=n_index, accumulate=t > 0)
+
+    if run.save:
+        x_needs = run.needs_grad(x)
+        if n_index is not None and x_needs:
+            raise NotImplementedError("coclr_amd: gathered conv input cannot require grad")
+
+        def backward():
+            dz = run.grad_of(out)
+            dy = torch.empty_like(y)
+            dgb = run.empty(2, Cout)
+            sums = run.empty(2 * Cout, dtype=torch.float64)
+            coef = run.empty(3 * Cout)
+            dres = None
+            dres_acc = False
+            if residual is not None and run.needs_grad(residual):
+                dres, dres_acc = run.grad_target(residual)
+            ops.bn_act_backward(dz, y, zv if residual is not None else None, scale, shift, mean,
+                                invstd, sums, coef, dy, dres, dgb[0], dgb[1], relu, training,
+                                dres_acc)
+            if bn.weight.requires_grad:
+                run.add_param_grad(bn.weight, dgb[0])
+            if bn.bias.requires_grad:
+                run.add_param_grad(bn.bias, dgb[1])
+            if w.requires_grad:
+                dw = torch.empty_like(w)
+                kk = w.shape[2] * w.shape[3] * w.shape[4]
+                for t, g in enumerate(geoms):
+                    ws = run.empty(g.wgrad_workspace())
+                    ops.conv_wgrad(g, xv, dy, dw, ws, Cin * kk, kk,
+                                   t * k[1] * k[2] if sliced else 0)
+                run.add_param_grad(w, dw)
+            if x_needs:
+                if sliced:
+                    raise NotImplementedError("coclr_amd: dgrad of the sliced stem conv")
+                dx, acc = run.grad_target(x)
+                ops.conv_fwd(geoms[0].dgrad(), dy, run.pack(w, True), dx, accumulate=acc)
+
+        run.tape.append(backward)
+    elif y is not None:
+        del y
+    return out
+
+
+# ---------------------------------------------------------------------------------
+# pooling
+# ---------------------------------------------------------------------------------
+
+def max_pool(run, x, kernel, stride, padding):
+    """nn.MaxPool3d (backbone/s3dg.py:105,151,162,173,190; resnet_2d3d.py:141)."""
+    N, Cc = x.shape[0], x.shape[1]
+    g = ops.PoolGeom(N, Cc, x.shape[2:], _triple(kernel), _triple(stride), _triple(padding))
+    y = run.empty(N, Cc, *g.odim)
+    need = run.needs_grad(x)
+    idx = run.empty(N, Cc, *g.odim, dtype=torch.int32) if need else None
+    ops.maxpool_fwd(g, x.view(), y, idx)
+    out = Val(y)
+    if need:
+        def backward():
+            dx, acc = run.grad_target(x)
+            ops.maxpool_bwd(g, run.grad_of(out), idx, dx, accumulate=acc)
+        run.tape.append(backward)
+    elif run.save:
+        run.no_grad_bases.add(id(y))
+    return out
+
+
+def subsample(run, x, stride):
+    """x[:, :, ::st, ::sh, ::sw] as a dense tensor (kernel-1 max pool)."""
+    return max_pool(run, x, (1, 1, 1), stride, (0, 0, 0))
+
+
+# ---------------------------------------------------------------------------------
+# S3D-G feature gating (backbone/s3dg.py:68-78).  Not used by any benchmarked
+# configuration; kept functional with device-side torch ops.
+# ---------------------------------------------------------------------------------
+
+def self_gating(run, x, fc, out=None):
+    xv = x.view()
+    a = xv.mean(dim=(2, 3, 4))
+    wgt = torch.sigmoid(torch.addmm(fc.bias, a, fc.weight.t()))
+    if out is None:
+        out = Val(torch.empty_like(xv))
+    torch.mul(xv, wgt[:, :, None, None, None], out=out.view())
+    if run.save:
+        def backward():
+            dout = run.grad_of(out)
+            dwgt = (dout * xv).sum(dim=(2, 3, 4))
+            ds = dwgt * wgt * (1 - wgt)
+            if fc.weight.requires_grad:
+                run.add_param_grad(fc.weight, ds.t().mm(a))
+                run.add_param_grad(fc.bias, ds.sum(0))
+            if run.needs_grad(x):
+                S = xv.shape[2] * xv.shape[3] * xv.shape[4]
+                dx = dout * wgt[:, :, None, None, None] + (ds.mm(fc.weight) / S)[:, :, None, None, None]
+                g, acc = run.grad_target(x)
+                if acc:
+                    g.add_(dx)
+                else:
+                    g.copy_(dx)
+        run.tape.append(backward)
+    return out
+
+
+# ---------------------------------------------------------------------------------
+# autograd bridge
+# ---------------------------------------------------------------------------------
+
+class EngineFn(torch.autograd.Function):
+    """backbone(x, *params) as ONE autograd node."""
+
+    @staticmethod
+    def forward(ctx, module, kwargs, x, *params):
+        need_dx = x.requires_grad
+        run = Run(x.device, save=True, need_input_grad=need_dx)
+        xin = Val(x if _dense5(x) else x.contiguous())
+        if not need_dx:
+            run.no_grad_bases.add(id(xin.base))
+        run.out = module._emit(run, xin, **kwargs)
+        ctx.run = run
+        ctx.xin = xin
+        ctx.params = params
+        ctx.need_dx = need_dx
+        out = run.out.view()
+        return out if out.is_contiguous() else out.contiguous()
+
+    @staticmethod
+    def backward(ctx, dout):
+        run = ctx.run
+        if run is None:
+            raise RuntimeError("coclr_amd: backbone backward called twice (graph not retained)")
+        ctx.run = None
+        run.backward(dout)
+        dx = run.grads.get(id(ctx.xin.base)) if ctx.need_dx else None
+        grads = tuple(run.param_grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+        return (None, None, dx) + grads
+
+
+def _dense5(t):
+    n, c, d, h, w = t.shape
+    s = t.stride()
+    return s[4] == 1 and s[3] == w and s[2] == h * w and s[1] == d * h * w
+
+
+def run_module(module, x, **kwargs):
+    """Forward `module` (anything with `_emit(run, val, **kw)`) on x."""
+    params = [p for p in module.parameters()]
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        return EngineFn.apply(module, kwargs, x, *params)
+    run = Run(x.device, save=False)
+    xin = Val(x if _dense5(x) else x.contiguous())
+    out = module._emit(run, xin, **kwargs).view()
+    return out if out.is_contiguous() else out.contiguous()

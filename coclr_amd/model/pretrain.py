@@ -1,0 +1,472 @@
+"""InfoNCE / UberNCE / CoCLR heads (MoCo for video) on the gfx950 kernel library.
+
+API, buffer names and step semantics follow the reference model/pretrain.py
+(InfoNCE :28-190, UberNCE :193-278, CoCLR :281-418, concat_all_gather :14-25);
+the launch scripts main_nce.py / main_coclr.py drive these classes unchanged.
+
+Differences are all below the API:
+  * encoders run on coclr_amd.engine (hand-written HIP conv/BN/pool kernels)
+  * the clip pair is consumed as strided views, never `.contiguous()`-copied
+    (ref :149-150), and the shuffle-BN row gather (ref :124) is folded into the
+    first conv of the key encoder as a sample-index indirection
+  * momentum update = one multi-tensor launch (ref :79-80 is ~700 launches)
+  * logits = one fused MFMA kernel writing [l_pos | l_neg]/T (ref :175-182)
+  * the queue pointer stays on the device (ref :89 syncs the host every step)
+  * keys cross ranks once: the un-shuffle gather (ref :134) and the enqueue
+    gather (ref :85) are the same all_gather_into_tensor over RCCL
+"""
+import torch
+import torch.nn as nn
+import torch.distributed as dist
+
+from .. import ops
+from ..backbone.select_backbone import select_backbone
+
+_CHUNK = 32768   # elements per workgroup of the momentum kernel
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+@torch.no_grad()
+def concat_all_gather(tensor):
+    """All-gather along dim 0 (no gradient), one RCCL all_gather_into_tensor
+    instead of the list API + torch.cat (ref :14-25)."""
+    world, _ = _world()
+    if world == 1:
+        return tensor
+    tensor = tensor.contiguous()
+    out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
+                      device=tensor.device)
+    dist.all_gather_into_tensor(out, tensor)
+    return out
+
+
+# ---------------------------------------------------------------------------------
+# head modules (indices 1..4 of the encoder nn.Sequential, ref :49-54)
+# ---------------------------------------------------------------------------------
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.shape = x.shape
+        y = torch.empty(x.shape[0], x.shape[1], 1, 1, 1, dtype=x.dtype, device=x.device)
+        ops.global_avgpool_fwd(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        ops.global_avgpool_bwd(dy.contiguous(), dx)
+        return dx
+
+
+class GlobalAvgPool3d(nn.AdaptiveAvgPool3d):
+    """nn.AdaptiveAvgPool3d((1,1,1)) on the HIP kernel."""
+
+    def forward(self, x):
+        if tuple(self.output_size) != (1, 1, 1):
+            raise NotImplementedError("coclr_amd: only global average pooling is implemented")
+        return _AvgPoolFn.apply(x)
+
+
+class _PointwiseFn(torch.autograd.Function):
+    """y[n][co] = sum_ci x[n][ci] w[co][ci] + b[co] on pooled (N,C,1,1,1) features."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        N, Cin = x.shape[0], x.shape[1]
+        Cout = w.shape[0]
+        x2 = x.reshape(N, Cin).contiguous()
+        w2 = w.reshape(Cout, Cin)
+        y = torch.empty(N, Cout, dtype=x.dtype, device=x.device)
+        ops.gemm(x2, Cin, 1, w2, 1, Cin, y, Cout, b, N, Cout, Cin)
+        ctx.save_for_backward(x2, w2)
+        ctx.has_bias = b is not None
+        return y.view(N, Cout, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w2 = ctx.saved_tensors
+        N, Cin = x2.shape
+        Cout = w2.shape[0]
+        dy2 = dy.reshape(N, Cout).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            ops.gemm(dy2, Cout, 1, w2, Cin, 1, dx, Cin, None, N, Cin, Cout)
+            dx = dx.view(N, Cin, 1, 1, 1)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w2)
+            # dw[co][ci] = sum_n dy[n][co] x[n][ci]
+            ops.gemm(dy2, 1, Cout, x2, Cin, 1, dw, Cin, None, Cout, Cin, N)
+            dw = dw.view(Cout, Cin, 1, 1, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, dtype=dy.dtype, device=dy.device)
+            ops.colsum(dy2, db)
+        return dx, dw, db
+
+
+class PointwiseConv3d(nn.Conv3d):
+    """nn.Conv3d(cin, cout, kernel_size=1, bias=True) of the projection head (ref :52,54);
+    constructed through nn.Conv3d so init and RNG use are identical."""
+
+    def forward(self, x):
+        if x.dim() != 5 or x.shape[2] * x.shape[3] * x.shape[4] != 1:
+            raise NotImplementedError(
+                "coclr_amd: projection-head conv expects globally pooled (N,C,1,1,1) input")
+        return _PointwiseFn.apply(x, self.weight, self.bias)
+
+
+class _ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ops.relu_fwd(x, y)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        ops.relu_bwd(dy.contiguous(), y, dx)
+        return dx
+
+
+class HeadReLU(nn.ReLU):
+    def forward(self, x):
+        return _ReluFn.apply(x)
+
+
+class _L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=1) on (B, D) rows (ref :154)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        inv = torch.empty(x.shape[0], dtype=x.dtype, device=x.device)
+        ops.l2norm_fwd(x, y, inv)
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        ops.l2norm_bwd(dy.contiguous(), y, inv, dx)
+        return dx
+
+
+class _NceLogitsFn(torch.autograd.Function):
+    """logits = cat([<q,k>, q @ queue], 1) / T with gradient to q only (ref :175-182)."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, T):
+        B, D = q.shape
+        K = queue.shape[1]
+        logits = torch.empty(B, 1 + K, dtype=q.dtype, device=q.device)
+        ops.nce_logits_fwd(q, k, queue, logits, T)
+        if ctx.needs_input_grad[0]:
+            # the enqueue that follows overwrites columns of `queue` in place
+            ctx.save_for_backward(k, queue.clone())
+        ctx.T = T
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        k, queue = ctx.saved_tensors
+        B, D = k.shape
+        K = queue.shape[1]
+        splits = max(1, min(K // 128, 256))
+        ws = torch.empty(max(1, ops.gemm_workspace(B, D, K, splits)), dtype=k.dtype,
+                         device=k.device)
+        dq = torch.empty(B, D, dtype=k.dtype, device=k.device)
+        ops.nce_logits_bwd(dlogits.contiguous(), k, queue, dq, ws, ctx.T, splits)
+        return dq, None, None, None
+
+
+def _make_encoder(network, dim):
+    backbone, param = select_backbone(network)
+    fs = param["feature_size"]
+    enc = nn.Sequential(backbone,
+                        GlobalAvgPool3d((1, 1, 1)),
+                        PointwiseConv3d(fs, fs, kernel_size=1, bias=True),
+                        HeadReLU(),
+                        PointwiseConv3d(fs, dim, kernel_size=1, bias=True))
+    return enc, param
+
+
+class InfoNCE(nn.Module):
+    """MoCo for video (ref :28-190)."""
+
+    def __init__(self, network='s3d', dim=128, K=2048, m=0.999, T=0.07):
+        super().__init__()
+        self.dim = dim
+        self.K = K
+        self.m = m
+        self.T = T
+
+        # construction order fixes the global-RNG stream: q backbone+head, k backbone+head, queue
+        self.encoder_q, self.param = _make_encoder(network, dim)
+        self.encoder_k, _ = _make_encoder(network, dim)
+        for param_q, param_k in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            param_k.data.copy_(param_q.data)
+            param_k.requires_grad = False
+
+        self.register_buffer("queue", torch.randn(dim, K))
+        self.queue = nn.functional.normalize(self.queue, dim=0)
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self._momentum_table = None
+
+    # -- momentum encoder ---------------------------------------------------------
+    def _build_momentum_table(self):
+        rows, sig = [], []
+        for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            if not (pq.is_contiguous() and pk.is_contiguous()):
+                raise RuntimeError("coclr_amd: encoder parameters must be contiguous")
+            sig.append((pq.data_ptr(), pk.data_ptr()))
+            n = pk.numel()
+            for off in range(0, n, _CHUNK):
+                rows.append((pk.data_ptr() + 4 * off, pq.data_ptr() + 4 * off,
+                             min(_CHUNK, n - off)))
+        dev = next(self.encoder_k.parameters()).device
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self._momentum_table = (tuple(sig), table, len(rows))
+
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        '''p_k <- p_k * m + p_q * (1 - m) for every parameter pair, one launch.'''
+        sig = tuple((pq.data_ptr(), pk.data_ptr())
+                    for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()))
+        if self._momentum_table is None or self._momentum_table[0] != sig:
+            self._build_momentum_table()
+        _, table, n = self._momentum_table
+        ops.momentum_update(table, n, float(self.m), float(1. - self.m))
+
+    # -- queue ---------------------------------------------------------------------
+    @torch.no_grad()
+    def _enqueue_gathered(self, keys_all, extra=()):
+        """keys_all: (B*world, dim) in global batch order."""
+        batch_size = keys_all.shape[0]
+        assert self.K % batch_size == 0  # for simplicity
+        ops.queue_enqueue(self.queue, keys_all.contiguous(), self.queue_ptr)
+        for qbuf, vals, const in extra:
+            ops.queue_fill_i64(qbuf, vals, const, batch_size, self.queue_ptr)
+        ops.queue_advance(self.queue_ptr, batch_size, self.K)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys):
+        self._enqueue_gathered(concat_all_gather(keys))
+
+    # -- shuffle BN ------------------------------------------------------------------
+    @torch.no_grad()
+    def _shuffle_indices(self, batch_size_this, device):
+        """Common permutation of the global batch: CPU randperm (same RNG stream as the
+        reference, ref :112) broadcast from rank 0."""
+        world, rank = _world()
+        batch_size_all = batch_size_this * world
+        idx_shuffle = torch.randperm(batch_size_all).to(device)
+        if world > 1:
+            dist.broadcast(idx_shuffle, src=0)
+        idx_unshuffle = torch.argsort(idx_shuffle)
+        idx_this = idx_shuffle.view(world, -1)[rank]
+        return idx_this, idx_unshuffle
+
+    @torch.no_grad()
+    def _batch_shuffle_ddp(self, x):
+        '''Same contract as the reference (:98-124): returns (x_shuffled, idx_unshuffle).'''
+        x_gather = concat_all_gather(x)
+        idx_this, idx_unshuffle = self._shuffle_indices(x.shape[0], x.device)
+        out = torch.empty((idx_this.shape[0],) + tuple(x_gather.shape[1:]), dtype=x.dtype,
+                          device=x.device)
+        ops.gather_rows(x_gather.contiguous(), idx_this.contiguous(), out)
+        return out, idx_unshuffle
+
+    @torch.no_grad()
+    def _batch_unshuffle_ddp(self, x, idx_unshuffle):
+        '''Same contract as the reference (:126-143).'''
+        world, rank = _world()
+        x_gather = concat_all_gather(x).contiguous()
+        idx_this = idx_unshuffle.view(world, -1)[rank].contiguous()
+        out = torch.empty((idx_this.shape[0],) + tuple(x_gather.shape[1:]), dtype=x.dtype,
+                          device=x.device)
+        ops.gather_rows(x_gather, idx_this, out)
+        return out
+
+    # -- encoders --------------------------------------------------------------------
+    def _encode(self, encoder, x, n_index=None):
+        """encoder(x) -> L2-normalised (B, dim); x may be a strided clip view."""
+        feat = encoder[0](x, n_index=n_index) if n_index is not None else encoder[0](x)
+        for mod in list(encoder)[1:]:
+            feat = mod(feat)
+        return _L2NormFn.apply(feat.view(feat.shape[0], self.dim))
+
+    @torch.no_grad()
+    def _encode_keys(self, x2):
+        """Key path: shuffle -> encoder_k -> normalise -> un-shuffle.
+        Returns (k for this rank's samples, keys of the whole global batch in order)."""
+        world, rank = _world()
+        B = x2.shape[0]
+        idx_this, idx_unshuffle = self._shuffle_indices(B, x2.device)
+        src = concat_all_gather(x2) if world > 1 else x2
+        k_shuf = self._encode(self.encoder_k, src, n_index=idx_this.contiguous())
+        k_all_shuf = concat_all_gather(k_shuf)
+        k_all = torch.empty_like(k_all_shuf)
+        ops.gather_rows(k_all_shuf.contiguous(), idx_unshuffle.contiguous(), k_all)
+        return k_all[rank * B:(rank + 1) * B], k_all
+
+    def _split_pair(self, block):
+        (B, N, *_) = block.shape  # [B,N,C,T,H,W]
+        assert N == 2
+        return block[:, 0], block[:, 1]
+
+    def forward(self, block):
+        '''Output: logits, targets'''
+        x1, x2 = self._split_pair(block)
+        B = x1.shape[0]
+
+        q = self._encode(self.encoder_q, x1)
+        in_train_mode = q.requires_grad
+
+        with torch.no_grad():
+            if in_train_mode:
+                self._momentum_update_key_encoder()
+            k, k_all = self._encode_keys(x2)
+
+        logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
+        labels = torch.zeros(B, dtype=torch.long, device=logits.device)
+
+        if in_train_mode:
+            self._enqueue_gathered(k_all)
+        return logits, labels
+
+
+def _bool_mask(mask_u8):
+    return mask_u8.view(torch.bool)
+
+
+class UberNCE(InfoNCE):
+    '''Supervised InfoNCE: positives are queue entries with the same label (ref :193-278).'''
+
+    def __init__(self, network='s3d', dim=128, K=2048, m=0.999, T=0.07):
+        super().__init__(network, dim, K, m, T)
+        self.register_buffer("queue_label", torch.ones(K, dtype=torch.long) * -1)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys, labels):
+        labels_all = concat_all_gather(labels).contiguous()
+        self._enqueue_gathered(concat_all_gather(keys), extra=[(self.queue_label, labels_all, 0)])
+
+    def forward(self, block, k_label):
+        '''Output: logits, binary mask for positive pairs'''
+        x1, x2 = self._split_pair(block)
+        B = x1.shape[0]
+
+        q = self._encode(self.encoder_q, x1)
+        in_train_mode = q.requires_grad
+
+        with torch.no_grad():
+            if in_train_mode:
+                self._momentum_update_key_encoder()
+            k, k_all = self._encode_keys(x2)
+
+        logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
+
+        # mask[:,0] = True, mask[:,1+j] = (k_label == queue_label[j])   (ref :267-269)
+        k_label = k_label.to(device=logits.device, dtype=torch.long).contiguous()
+        mask = torch.empty(B, 1 + self.K, dtype=torch.uint8, device=logits.device)
+        ops.positive_mask(None, k_label, self.queue_label, mask, 0)
+
+        if in_train_mode:
+            labels_all = concat_all_gather(k_label).contiguous()
+            self._enqueue_gathered(k_all, extra=[(self.queue_label, labels_all, 0)])
+        return logits, _bool_mask(mask)
+
+
+class CoCLR(InfoNCE):
+    '''CoCLR: positives mined in the queue of the other modality (ref :281-418).'''
+
+    def __init__(self, network='s3d', dim=128, K=2048, m=0.999, T=0.07, topk=5, reverse=False):
+        super().__init__(network, dim, K, m, T)
+        self.topk = topk
+
+        # frozen encoder of the second view
+        self.sampler, _ = _make_encoder(network, dim)
+        for param_s in self.sampler.parameters():
+            param_s.requires_grad = False
+
+        self.register_buffer("queue_second", torch.randn(dim, K))
+        self.queue_second = nn.functional.normalize(self.queue_second, dim=0)
+        self.register_buffer("queue_vname", torch.ones(K, dtype=torch.long) * -1)
+        self.register_buffer("queue_label", torch.ones(K, dtype=torch.long) * -1)
+
+        self.queue_is_full = False
+        self.reverse = reverse
+
+    @torch.no_grad()
+    def _enqueue_coclr(self, keys_all, keys_second_all, vnames_all):
+        batch_size = keys_all.shape[0]
+        assert self.K % batch_size == 0  # for simplicity
+        ops.queue_enqueue(self.queue, keys_all.contiguous(), self.queue_ptr)
+        ops.queue_enqueue(self.queue_second, keys_second_all.contiguous(), self.queue_ptr)
+        ops.queue_fill_i64(self.queue_vname, vnames_all.contiguous(), 0, batch_size,
+                           self.queue_ptr)
+        ops.queue_fill_i64(self.queue_label, None, 1, batch_size, self.queue_ptr)
+        ops.queue_advance(self.queue_ptr, batch_size, self.K)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys, keys_second, vnames):
+        self._enqueue_coclr(concat_all_gather(keys), concat_all_gather(keys_second),
+                            concat_all_gather(vnames))
+
+    def forward(self, block1, block2, k_vsource):
+        '''Output: logits, targets'''
+        x1, f1 = self._split_pair(block1)
+        x2, f2 = self._split_pair(block2)
+        if self.reverse:
+            x1, f1 = f1, x1
+            x2, f2 = f2, x2
+        B = x1.shape[0]
+
+        q = self._encode(self.encoder_q, x1)
+        in_train_mode = q.requires_grad
+
+        with torch.no_grad():
+            if in_train_mode:
+                self._momentum_update_key_encoder()
+            k, k_all = self._encode_keys(x2)
+            # second view: frozen sampler (eval-mode BN in the reference's training loop),
+            # not shuffled
+            kf = self._encode(self.sampler, f2)
+
+        logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
+
+        k_vsource = k_vsource.to(device=logits.device, dtype=torch.long).contiguous()
+        if not self.queue_is_full:
+            # one host sync per step until the queue has wrapped once (ref :400-402); a
+            # plain bool afterwards so the steady state never blocks on the device
+            self.queue_is_full = bool(torch.all(self.queue_label != -1))
+            if self.queue_is_full:
+                print('\n===== queue is full now =====')
+
+        mask = torch.empty(B, 1 + self.K, dtype=torch.uint8, device=logits.device)
+        if self.queue_is_full and (self.topk != 0):
+            # cross-modal similarity against the second queue, top-k mined per row with
+            # same-source (sibling) entries excluded (ref :405-410)
+            sim = torch.empty(B, self.K, dtype=kf.dtype, device=kf.device)
+            ops.gemm(kf, self.dim, 1, self.queue_second, self.K, 1, sim, self.K, None, B, self.K,
+                     self.dim)
+            ops.positive_mask(sim, k_vsource, self.queue_vname, mask, int(self.topk))
+        else:
+            ops.positive_mask(None, k_vsource, self.queue_vname, mask, 0)
+
+        if in_train_mode:
+            self._enqueue_coclr(k_all, concat_all_gather(kf), concat_all_gather(k_vsource))
+        return logits, _bool_mask(mask).detach()

@@ -1,0 +1,307 @@
+"""Tensor-level wrappers over the C ABI in include/coclr_hip.h.
+
+Every function here takes device tensors (possibly channel-slice views of
+wider NCDHW buffers), extracts raw pointers / strides and enqueues the HIP
+kernel on torch's *current* stream.  Nothing is computed in Python or by
+ATen, and there is no CPU path: host tensors are rejected.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, PoolDesc
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.HipLibraryError(
+            "coclr_amd: kernels need device tensors (got %s); there is no CPU fallback" % t.device)
+    if t.dtype != dtype:
+        raise TypeError("coclr_amd: expected %s tensor, got %s" % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _chk5(t, name):
+    """NCDHW view whose (C,T,H,W) part is dense; returns the sample stride."""
+    n, c, d, h, w = t.shape
+    s = t.stride()
+    if not (s[4] == 1 and s[3] == w and s[2] == h * w and s[1] == d * h * w) and t.numel() > 0:
+        raise ValueError("coclr_amd: %s must be dense in (C,T,H,W); strides %s shape %s" %
+                         (name, s, tuple(t.shape)))
+    return s[0] if n > 1 else max(s[0], c * d * h * w)
+
+
+class ConvGeom:
+    """Geometry of one 3D convolution (python mirror of coclr_conv_desc)."""
+
+    __slots__ = ("N", "Cin", "Cout", "idim", "odim", "k", "s", "p", "d", "desc", "_cache")
+
+    def __init__(self, N, Cin, Cout, idim, k, s, p, d=(1, 1, 1), odim=None):
+        self.N, self.Cin, self.Cout = int(N), int(Cin), int(Cout)
+        self.idim = tuple(int(v) for v in idim)
+        self.k, self.s, self.p, self.d = (tuple(int(v) for v in t) for t in (k, s, p, d))
+        if odim is None:
+            odim = tuple(((self.idim[i] - 1) * self.d[i] + 1 + 2 * self.p[i] - self.k[i]) //
+                         self.s[i] + 1 for i in range(3))
+        self.odim = tuple(int(v) for v in odim)
+        if min(self.odim) <= 0:
+            raise ValueError("coclr_amd: convolution output would be empty: in %s k %s s %s p %s" %
+                             (self.idim, self.k, self.s, self.p))
+        self.desc = ConvDesc(self.N, self.Cin, self.Cout, *self.idim, *self.odim, *self.k,
+                             *self.s, *self.p, *self.d, 0, 0)
+        self._cache = {}
+
+    @property
+    def taps(self):
+        return self.k[0] * self.k[1] * self.k[2]
+
+    def dgrad(self):
+        """Geometry of the data-gradient pass expressed as a forward call:
+        stride-1 correlation of the zero-upsampled dY with the flipped stencil."""
+        g = self._cache.get("dgrad")
+        if g is None:
+            pad = tuple(self.k[i] - 1 - self.p[i] for i in range(3))
+            if min(pad) < 0:
+                raise ValueError("coclr_amd: padding larger than kernel-1 is not supported")
+            g = ConvGeom(self.N, self.Cout, self.Cin, self.odim, self.k, (1, 1, 1), pad,
+                         d=self.s, odim=self.idim)
+            self._cache["dgrad"] = g
+        return g
+
+    def ntiles(self):
+        v = self._cache.get("ntiles")
+        if v is None:
+            out = C.c_int32(0)
+            _lib.check(_lib.load().coclr_conv3d_ntiles(C.byref(self.desc), C.byref(out)),
+                       "conv3d_ntiles %s" % self)
+            v = self._cache["ntiles"] = out.value
+        return v
+
+    def wgrad_workspace(self):
+        v = self._cache.get("wgws")
+        if v is None:
+            out = C.c_int64(0)
+            _lib.check(_lib.load().coclr_conv3d_wgrad_workspace(C.byref(self.desc), C.byref(out)),
+                       "conv3d_wgrad_workspace %s" % self)
+            v = self._cache["wgws"] = out.value
+        return v
+
+    def __repr__(self):
+        return "ConvGeom(N=%d, %d->%d, in=%s, out=%s, k=%s, s=%s, p=%s, d=%s)" % (
+            self.N, self.Cin, self.Cout, self.idim, self.odim, self.k, self.s, self.p, self.d)
+
+
+class PoolGeom:
+    __slots__ = ("N", "C", "idim", "odim", "k", "s", "p", "desc")
+
+    def __init__(self, N, Cc, idim, k, s, p):
+        self.N, self.C = int(N), int(Cc)
+        self.idim = tuple(int(v) for v in idim)
+        self.k, self.s, self.p = (tuple(int(v) for v in t) for t in (k, s, p))
+        self.odim = tuple((self.idim[i] + 2 * self.p[i] - self.k[i]) // self.s[i] + 1
+                          for i in range(3))
+        if min(self.odim) <= 0:
+            raise ValueError("coclr_amd: pooling output would be empty")
+        self.desc = PoolDesc(self.N, self.C, *self.idim, *self.odim, *self.k, *self.s, *self.p, 0, 0)
+
+
+# ---- convolution ---------------------------------------------------------------
+
+def conv_packed_size(cin, cout, taps, transpose):
+    out = C.c_int64(0)
+    _lib.check(_lib.load().coclr_conv_packed_size(cin, cout, taps, int(transpose), C.byref(out)),
+               "conv_packed_size")
+    return out.value
+
+
+def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose):
+    _lib.check(_lib.load().coclr_conv_pack_weights(
+        _p(w), _p(packed), cout, cin, taps, co_stride, ci_stride, tap_base, int(transpose),
+        _stream()), "conv_pack_weights")
+
+
+def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shift=None,
+             n_index=None, relu=False, accumulate=False):
+    d = geom.desc
+    d.x_nstride = _chk5(x, "x")
+    d.y_nstride = _chk5(y, "y")
+    _lib.check(_lib.load().coclr_conv3d_fwd(
+        C.byref(d), _p(x), _p(w_packed), _p(y), _p(stats), _p(bias), _p(ep_scale), _p(ep_shift),
+        _p(n_index, torch.int64), int(relu), int(accumulate), _stream()), "conv3d_fwd %s" % geom)
+
+
+def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accumulate=False):
+    d = geom.desc
+    d.x_nstride = _chk5(x, "x")
+    d.y_nstride = _chk5(dy, "dy")
+    _lib.check(_lib.load().coclr_conv3d_wgrad(
+        C.byref(d), _p(x), _p(dy), _p(dw), _p(workspace), co_stride, ci_stride, tap_base,
+        int(accumulate), _stream()), "conv3d_wgrad %s" % geom)
+
+
+# ---- batch norm ------------------------------------------------------------------
+
+def bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt, momentum,
+                eps, mean, invstd, scale, shift):
+    _lib.check(_lib.load().coclr_bn_finalize(
+        _p(stats), C_, ntiles, float(count), _p(gamma), _p(beta), _p(running_mean),
+        _p(running_var), _p(nbt, torch.int64), momentum, eps, _p(mean), _p(invstd), _p(scale),
+        _p(shift), _stream()), "bn_finalize")
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps, C_, mean, invstd, scale, shift):
+    _lib.check(_lib.load().coclr_bn_eval_affine(
+        _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C_, _p(mean), _p(invstd),
+        _p(scale), _p(shift), _stream()), "bn_eval_affine")
+
+
+def bn_act_apply(y, scale, shift, residual, z, relu):
+    N, C_, T, H, W = y.shape
+    S = T * H * W
+    if not y.is_contiguous():
+        raise ValueError("coclr_amd: bn_act_apply expects contiguous y")
+    _lib.check(_lib.load().coclr_bn_act_apply(
+        _p(y), _p(scale), _p(shift), _p(residual), _p(z), N, C_, S, _chk5(z, "z"),
+        _chk5(residual, "residual") if residual is not None else 0, int(relu), _stream()),
+        "bn_act_apply")
+
+
+def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, coef_ws, dy, dres, dgamma,
+                    dbeta, relu, training, dres_accumulate=False):
+    N, C_, T, H, W = y.shape
+    S = T * H * W
+    if not (y.is_contiguous() and dy.is_contiguous()):
+        raise ValueError("coclr_amd: bn_act_backward expects contiguous y/dy")
+    _lib.check(_lib.load().coclr_bn_act_backward(
+        _p(dz), _p(y), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd),
+        _p(sums_ws, torch.float64), _p(coef_ws), _p(dy), _p(dres), _p(dgamma), _p(dbeta), N, C_, S,
+        _chk5(dz, "dz"), _chk5(z, "z") if z is not None else 0,
+        _chk5(dres, "dres") if dres is not None else 0, int(relu), int(training),
+        int(dres_accumulate), _stream()), "bn_act_backward")
+
+
+# ---- pooling ---------------------------------------------------------------------
+
+def maxpool_fwd(geom, x, y, indices=None):
+    d = geom.desc
+    d.x_nstride = _chk5(x, "x")
+    d.y_nstride = _chk5(y, "y")
+    _lib.check(_lib.load().coclr_maxpool3d_fwd(C.byref(d), _p(x), _p(y),
+                                               _p(indices, torch.int32), _stream()),
+               "maxpool3d_fwd")
+
+
+def maxpool_bwd(geom, dy, indices, dx, accumulate=False):
+    _lib.check(_lib.load().coclr_maxpool3d_bwd(
+        C.byref(geom.desc), _p(dy), _p(indices, torch.int32), _p(dx), _chk5(dy, "dy"),
+        _chk5(dx, "dx"), int(accumulate), _stream()), "maxpool3d_bwd")
+
+
+def global_avgpool_fwd(x, y):
+    planes = x.shape[0] * x.shape[1]
+    _lib.check(_lib.load().coclr_global_avgpool_fwd(_p(x), _p(y), planes, x.numel() // planes,
+                                                    _stream()), "global_avgpool_fwd")
+
+
+def global_avgpool_bwd(dy, dx):
+    planes = dx.shape[0] * dx.shape[1]
+    _lib.check(_lib.load().coclr_global_avgpool_bwd(_p(dy), _p(dx), planes, dx.numel() // planes,
+                                                    _stream()), "global_avgpool_bwd")
+
+
+# ---- head --------------------------------------------------------------------------
+
+def gemm_workspace(M, N, K, splits):
+    out = C.c_int64(0)
+    _lib.check(_lib.load().coclr_gemm_workspace(M, N, K, splits, C.byref(out)), "gemm_workspace")
+    return out.value
+
+
+def gemm(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha=1.0, relu=False, accumulate=False,
+         splits=1, workspace=None):
+    _lib.check(_lib.load().coclr_gemm(
+        _p(a), sam, sak, _p(b), sbk, sbn, _p(c), ldc, _p(bias), M, N, K, alpha, int(relu),
+        int(accumulate), splits, _p(workspace), _stream()), "gemm")
+
+
+def l2norm_fwd(x, y, inv_norm, eps=1e-12):
+    rows, D = x.shape
+    _lib.check(_lib.load().coclr_l2norm_fwd(_p(x), _p(y), _p(inv_norm), rows, D, eps, _stream()),
+               "l2norm_fwd")
+
+
+def l2norm_bwd(dy, y, inv_norm, dx):
+    rows, D = y.shape
+    _lib.check(_lib.load().coclr_l2norm_bwd(_p(dy), _p(y), _p(inv_norm), _p(dx), rows, D,
+                                            _stream()), "l2norm_bwd")
+
+
+def nce_logits_fwd(q, k, queue, logits, T):
+    B, D = q.shape
+    K = queue.shape[1]
+    _lib.check(_lib.load().coclr_nce_logits_fwd(_p(q), _p(k), _p(queue), _p(logits), B, D, K, T,
+                                                _stream()), "nce_logits_fwd")
+
+
+def nce_logits_bwd(dlogits, k, queue, dq, workspace, T, splits):
+    B, D = dq.shape
+    K = queue.shape[1]
+    _lib.check(_lib.load().coclr_nce_logits_bwd(_p(dlogits), _p(k), _p(queue), _p(dq),
+                                                _p(workspace), B, D, K, T, splits, _stream()),
+               "nce_logits_bwd")
+
+
+def momentum_update(table, nchunks, m, one_minus_m):
+    _lib.check(_lib.load().coclr_momentum_update(_p(table, torch.int64), nchunks, m, one_minus_m,
+                                                 _stream()), "momentum_update")
+
+
+def queue_enqueue(queue, keys, ptr):
+    D, K = queue.shape
+    BW = keys.shape[0]
+    _lib.check(_lib.load().coclr_queue_enqueue(_p(queue), _p(keys), D, K, BW,
+                                               _p(ptr, torch.int64), _stream()), "queue_enqueue")
+
+
+def queue_fill_i64(queue, vals, const_val, BW, ptr):
+    _lib.check(_lib.load().coclr_queue_fill_i64(
+        _p(queue, torch.int64), _p(vals, torch.int64), const_val, queue.shape[0], BW,
+        _p(ptr, torch.int64), _stream()), "queue_fill_i64")
+
+
+def queue_advance(ptr, BW, K):
+    _lib.check(_lib.load().coclr_queue_advance(_p(ptr, torch.int64), BW, K, _stream()),
+               "queue_advance")
+
+
+def positive_mask(sim, src, names, mask, topk):
+    B, K1 = mask.shape
+    _lib.check(_lib.load().coclr_positive_mask(
+        _p(sim), _p(src, torch.int64), _p(names, torch.int64), _p(mask, torch.uint8), B, K1 - 1,
+        topk, _stream()), "positive_mask")
+
+
+def gather_rows(inp, idx, out):
+    rows = out.shape[0]
+    _lib.check(_lib.load().coclr_gather_rows(_p(inp), _p(idx, torch.int64), _p(out), rows,
+                                             out.numel() // rows, _stream()), "gather_rows")
+
+
+def relu_fwd(x, y):
+    _lib.check(_lib.load().coclr_relu_fwd(_p(x), _p(y), x.numel(), _stream()), "relu_fwd")
+
+
+def relu_bwd(dy, y, dx):
+    _lib.check(_lib.load().coclr_relu_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream()), "relu_bwd")
+
+
+def colsum(x, out):
+    rows, cols = x.shape
+    _lib.check(_lib.load().coclr_colsum(_p(x), _p(out), rows, cols, _stream()), "colsum")

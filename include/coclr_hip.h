@@ -1,0 +1,208 @@
+/*
+ * coclr_hip.h -- C ABI of libcoclr_hip.so, the gfx950 (MI355X / CDNA4) kernel
+ * library under the CoCLR training hot path.
+ *
+ * The reference (TengdaHan/CoCLR) has no FFI of its own: every FLOP of
+ * model/pretrain.py and backbone/{s3dg,resnet_2d3d}.py is an implicit call
+ * into ATen/cuDNN/NCCL.  Each entry point below therefore cites the ATen op
+ * *call site* in the reference that it replaces (file:line under the
+ * reference root).  The Python host (coclr_amd/) binds these with ctypes;
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - all tensors are device pointers to contiguous fp32 unless noted,
+ *     NCDHW for activations, [Cout][Cin][kt][kh][kw] for conv weights
+ *   - every function enqueues work on `stream` (a hipStream_t passed as
+ *     void*; NULL = the legacy default stream), never synchronises, never
+ *     allocates device memory and keeps no pointer after returning
+ *   - return value: 0 on success, otherwise a hipError_t value
+ *     (1 == hipErrorInvalidValue is also used for rejected arguments)
+ *   - "nstride" arguments are the distance in floats between consecutive
+ *     samples, so a tensor may be a channel slice of a wider buffer
+ */
+#ifndef COCLR_HIP_H_
+#define COCLR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Convolution (backbone/s3dg.py:11-13,25,39-42,59,62;                      */
+/*              backbone/resnet_2d3d.py:53-59,67-79,138,192; head convs      */
+/*              model/pretrain.py:52,54 when applied to un-pooled maps)      */
+/* ------------------------------------------------------------------------ */
+
+typedef struct coclr_conv_desc {
+  int32_t N, Cin, Cout;
+  int32_t Ti, Hi, Wi;      /* input extent  */
+  int32_t To, Ho, Wo;      /* output extent */
+  int32_t kt, kh, kw;      /* stencil       */
+  int32_t st, sh, sw;      /* stride        */
+  int32_t pt, ph, pw;      /* zero padding  */
+  int32_t dt, dh, dw;      /* input dilation (zero insertion); 1 for a forward conv,
+                              = forward stride when the call computes a data gradient */
+  int64_t x_nstride;       /* floats between input samples  (>= Cin*Ti*Hi*Wi)  */
+  int64_t y_nstride;       /* floats between output samples (>= Cout*To*Ho*Wo) */
+} coclr_conv_desc;
+
+/* Number of fp32 elements of the packed-weight buffer for one conv. */
+int coclr_conv_packed_size(int cin, int cout, int taps, int transpose, int64_t* elems);
+
+/* Re-lay [Cout][Cin][taps] weights as [taps][Cin'][Cout'] (zero padded to x32).
+ * transpose=0: operand of the forward conv; transpose=1: operand of the data
+ * gradient (roles of Cin/Cout swapped, stencil flipped).  co/ci strides and
+ * tap_base let a (kt,kh,kw) stencil be addressed one kt-slice at a time. */
+int coclr_conv_pack_weights(const float* w, float* packed, int cout, int cin, int taps,
+                            int64_t co_stride, int64_t ci_stride, int tap_base, int transpose,
+                            void* stream);
+
+/* Number of per-workgroup BatchNorm partial sums coclr_conv3d_fwd will emit
+ * per channel for this geometry (stats buffer = 2 * Cout * ntiles floats). */
+int coclr_conv3d_ntiles(const coclr_conv_desc* d, int* ntiles);
+
+/* y (+)= act(affine(conv(x, w) + bias)).  Replaces aten::conv3d forward and,
+ * with transposed weights + input dilation, the dgrad half of
+ * aten::convolution_backward.  stats (optional): [2][Cout][ntiles] partial
+ * sum / sum-of-squares of the raw conv output for train-mode BatchNorm
+ * (backbone/s3dg.py:16,46-47).  n_index (optional): x sample n is read from
+ * sample n_index[n] -- the shuffle-BN row gather of model/pretrain.py:124
+ * folded into the first conv. */
+int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const float* w_packed, float* y,
+                     float* stats, const float* bias, const float* ep_scale,
+                     const float* ep_shift, const int64_t* n_index, int relu, int accumulate,
+                     void* stream);
+
+/* Split-K workspace (fp32 elements) for coclr_conv3d_wgrad. */
+int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* elems);
+
+/* dw[co][ci][tap] (+)= sum_{n,o} dy[n][co][o] * x[n][ci][o*s - p + tap]: the wgrad
+ * half of aten::convolution_backward.  dw is addressed as
+ * dw[co*w_co_stride + ci*w_ci_stride + tap_base + tap]. */
+int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, const float* dy, float* dw,
+                       float* workspace, int64_t w_co_stride, int64_t w_ci_stride, int tap_base,
+                       int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* BatchNorm3d + ReLU (+ residual)  (backbone/s3dg.py:16-17,26-27,46-48,     */
+/*                                   60-64; backbone/resnet_2d3d.py:54-83)   */
+/* ------------------------------------------------------------------------ */
+
+/* Fold the conv partial sums: batch mean / invstd, fused scale = gamma*invstd
+ * and shift = beta - mean*scale; momentum update of running_mean /
+ * running_var (unbiased) and num_batches_tracked += 1 (aten::batch_norm,
+ * training=True). */
+int coclr_bn_finalize(const float* stats, int C, int ntiles, double count, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, float eps, float* mean,
+                      float* invstd, float* scale, float* shift, void* stream);
+
+/* Eval-mode coefficients from the running statistics (main_coclr.py:363). */
+int coclr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int C, float* mean, float* invstd,
+                         float* scale, float* shift, void* stream);
+
+/* z = act(y*scale[c] + shift[c] (+ residual)); y contiguous [N][C][S]. */
+int coclr_bn_act_apply(const float* y, const float* scale, const float* shift,
+                       const float* residual, float* z, int N, int C, int64_t S, int64_t z_nstride,
+                       int64_t res_nstride, int relu, void* stream);
+
+/* Backward of the above (aten::threshold_backward + native_batch_norm_backward):
+ * dy, dgamma, dbeta and, for residual units, dres (+)= masked dz.
+ * z may be NULL (ReLU mask is then recomputed from y).  sums_ws: 2*C doubles,
+ * coef_ws: 3*C floats. */
+int coclr_bn_act_backward(const float* dz, const float* y, const float* z, const float* scale,
+                          const float* shift, const float* mean, const float* invstd,
+                          double* sums_ws, float* coef_ws, float* dy, float* dres, float* dgamma,
+                          float* dbeta, int N, int C, int64_t S, int64_t dz_nstride,
+                          int64_t z_nstride, int64_t dres_nstride, int relu, int training,
+                          int dres_accumulate, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Pooling (backbone/s3dg.py:105,151,162,173,190; resnet_2d3d.py:141;        */
+/*          model/pretrain.py:51)                                            */
+/* ------------------------------------------------------------------------ */
+
+typedef struct coclr_pool_desc {
+  int32_t N, C;
+  int32_t Ti, Hi, Wi, To, Ho, Wo;
+  int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int64_t x_nstride, y_nstride;
+} coclr_pool_desc;
+
+/* aten::max_pool3d_with_indices (floor mode, -inf padding, first max wins);
+ * indices (optional, [N][C][To*Ho*Wo] int32) = flat offset inside the input plane. */
+int coclr_maxpool3d_fwd(const coclr_pool_desc* d, const float* x, float* y, int32_t* indices,
+                        void* stream);
+/* aten::max_pool3d_with_indices_backward, gather form (deterministic). */
+int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, const int32_t* indices, float* dx,
+                        int64_t dy_nstride, int64_t dx_nstride, int accumulate, void* stream);
+/* aten::adaptive_avg_pool3d(x, (1,1,1)) and its backward; planes = N*C. */
+int coclr_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t S, void* stream);
+int coclr_global_avgpool_bwd(const float* dy, float* dx, int64_t planes, int64_t S, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Contrastive head (model/pretrain.py)                                      */
+/* ------------------------------------------------------------------------ */
+
+/* C[m][n] (+)= act(alpha * sum_k A(m,k)*B(k,n) + bias[n]) on the fp32 MFMA;
+ * A(m,k) = a[m*sam + k*sak], B(k,n) = b[k*sbk + n*sbn].  splits > 1 selects
+ * split-K through `workspace` (coclr_gemm_workspace elements).  Used for the
+ * projection-head 1x1x1 convs on pooled features (pretrain.py:52,54), their
+ * backward, and the similarity products below. */
+int coclr_gemm_workspace(int M, int N, int K, int splits, int64_t* elems);
+int coclr_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk, int64_t sbn,
+               float* c, int64_t ldc, const float* bias, int M, int N, int K, float alpha, int relu,
+               int accumulate, int splits, float* workspace, void* stream);
+
+/* F.normalize(x, dim=1) over rows of D (pretrain.py:154,167,380) and backward. */
+int coclr_l2norm_fwd(const float* x, float* y, float* inv_norm, int rows, int D, float eps,
+                     void* stream);
+int coclr_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int rows,
+                     int D, void* stream);
+
+/* logits[B][1+K] = [ <q_b,k_b> | q . queue ] / T  (pretrain.py:175-182: two einsums,
+ * queue.clone(), cat and the in-place divide in one pass). queue is [D][K]. */
+int coclr_nce_logits_fwd(const float* q, const float* k, const float* queue, float* logits, int B,
+                         int D, int K, float T, void* stream);
+/* dq = (dlogits[:,1:] . queue^T + dlogits[:,0] * k) / T ; workspace as coclr_gemm(B, D, K, splits). */
+int coclr_nce_logits_bwd(const float* dlogits, const float* k, const float* queue, float* dq,
+                         float* workspace, int B, int D, int K, float T, int splits, void* stream);
+
+/* p_k = p_k*m + p_q*(1-m) over many tensors in one launch (pretrain.py:76-80).
+ * table: int64[3*nchunks] on device = {dst ptr, src ptr, count<=65536} per chunk. */
+int coclr_momentum_update(const int64_t* table, int nchunks, float m, float one_minus_m,
+                          void* stream);
+
+/* queue[:, ptr:ptr+BW] = keys^T with ptr read on device (pretrain.py:89-93 without the
+ * int(queue_ptr) host sync); int64 side queues (pretrain.py:217,337-338); ptr=(ptr+BW)%K. */
+int coclr_queue_enqueue(float* queue, const float* keys, int D, int K, int BW, const int64_t* ptr,
+                        void* stream);
+int coclr_queue_fill_i64(int64_t* queue, const int64_t* vals, int64_t const_val, int K, int BW,
+                         const int64_t* ptr, void* stream);
+int coclr_queue_advance(int64_t* ptr, int BW, int K, void* stream);
+
+/* mask[B][1+K] (bytes): col 0 = 1; col 1+j = (src[b]==names[j]) or j among the topk
+ * largest sim[b][:] after same-source columns are set to -inf
+ * (pretrain.py:397-413; with topk=0 also UberNCE's label mask, pretrain.py:267-269). */
+int coclr_positive_mask(const float* sim, const int64_t* src, const int64_t* names, uint8_t* mask,
+                        int B, int K, int topk, void* stream);
+
+/* out[i][:] = in[idx[i]][:] (pretrain.py:124,143). */
+int coclr_gather_rows(const float* in, const int64_t* idx, float* out, int rows, int64_t row_elems,
+                      void* stream);
+
+/* nn.ReLU of the projection head (pretrain.py:53) and small helpers. */
+int coclr_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int coclr_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+int coclr_colsum(const float* x, float* out, int rows, int cols, void* stream);
+
+/* Library/ABI version, bumped when a signature changes. */
+int coclr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COCLR_HIP_H_ */

@@ -1,0 +1,123 @@
+"""Shared helpers: rebuild the inputs of a golden case (see oracle/make_golden.py) and
+compare a training step against the recorded reference outputs."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# tolerance of BASELINE.json's north_star: 1e-3 relative fp32 on logits / loss / queue
+REL_TOL = 1e-3
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN_DIR, name + ".pt"), weights_only=False)
+
+
+def case_inputs(cfg, step, world=1):
+    """Global-batch inputs of one step, exactly as make_golden.run_case draws them."""
+    B, kind = cfg["B"], cfg["kind"]
+    g = torch.Generator().manual_seed(cfg["input_seed"] + step)
+    nblk = 2 if kind == "coclr" else 1
+    blocks = [torch.randn(B * world, 2, *cfg["clip"], generator=g) for _ in range(nblk)]
+    extra = None
+    if kind == "ubernce":
+        extra = torch.randint(0, cfg["n_classes"], (B * world,), generator=g)
+    if kind == "coclr":
+        extra = torch.randint(0, cfg["n_sources"], (B * world,), generator=g)
+    return blocks, extra
+
+
+def build_model(cfg, module):
+    """Construct InfoNCE/UberNCE/CoCLR from `module` (reference-compatible namespace)
+    with the case's seed and queue prefill."""
+    torch.manual_seed(cfg["model_seed"])
+    kind = cfg["kind"]
+    args = (cfg["network"], cfg["dim"], cfg["K"], cfg["m"], cfg["T"])
+    if kind == "infonce":
+        model = module.InfoNCE(*args)
+    elif kind == "ubernce":
+        model = module.UberNCE(*args)
+    else:
+        model = module.CoCLR(*args, topk=cfg["topk"], reverse=cfg.get("reverse", False))
+        if cfg.get("prefill"):
+            g = torch.Generator().manual_seed(cfg["prefill"])
+            model.queue_label.fill_(1)
+            model.queue_vname.copy_(torch.randint(0, cfg["n_sources"], (cfg["K"],), generator=g))
+    return model
+
+
+def loss_fn(kind, out, tgt):
+    if kind == "infonce":
+        return F.cross_entropy(out, tgt)
+    if kind == "ubernce":
+        return (- (F.log_softmax(out, dim=1) * tgt).sum(1) / tgt.sum(1)).mean()
+    return (- torch.log((F.softmax(out, dim=1) * tgt).sum(1))).mean()
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu().reshape(-1)
+    ref = ref.detach().double().cpu().reshape(-1)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def sample(t, limit=4096):
+    flat = t.detach().reshape(-1)
+    if flat.numel() <= limit:
+        return flat
+    step = flat.numel() // limit
+    return flat[::step][:limit]
+
+
+def check_close(got, ref, tol, what):
+    e = rel_err(got, ref)
+    assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+
+
+def checksum_table(sd, keys):
+    return torch.tensor([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())]
+                         for k in keys], dtype=torch.float64).reshape(len(keys), 2)
+
+
+def compare_step(rec, kind, out, tgt, loss, named_grads, tol=REL_TOL, grad_tol=None):
+    """logits / target / loss / sampled grads of one step vs the golden record."""
+    grad_tol = grad_tol or 5 * tol
+    check_close(out, rec["logits"], tol, "logits")
+    if kind == "infonce":
+        assert torch.equal(tgt.cpu(), rec["target"]), "labels"
+    else:
+        assert torch.equal(tgt.cpu().nonzero(), rec["target"]), "positive mask"
+    check_close(loss, rec["loss"], max(tol, 2e-3), "loss")
+    for k, ref in rec["grads"].items():
+        check_close(sample(named_grads[k]), ref, grad_tol, "grad " + k)
+
+
+def compare_state(rec, sd, B_world, K, tol=REL_TOL):
+    """queue / pointer / BN buffers / updated params after the optimizer step."""
+    assert int(sd["queue_ptr"]) == int(rec["queue_ptr"]), "queue_ptr"
+    ptr0 = (int(sd["queue_ptr"]) - B_world) % K
+    check_close(sd["queue"][:, ptr0:ptr0 + B_world], rec["queue_cols"], tol, "queue columns")
+    cs = torch.tensor([float(sd["queue"].double().sum()), float(sd["queue"].double().abs().sum())])
+    assert abs(cs[1] - rec["queue_checksum"][1]) <= tol * abs(rec["queue_checksum"][1])
+    for k in ("queue_label", "queue_vname"):
+        if k + "_cols" in rec:
+            assert torch.equal(sd[k][ptr0:ptr0 + B_world].cpu(), rec[k + "_cols"]), k
+    if "queue_second_cols" in rec:
+        check_close(sd["queue_second"][:, ptr0:ptr0 + B_world], rec["queue_second_cols"], tol,
+                    "queue_second columns")
+    for k, ref in rec["buffers"].items():
+        if ref.is_floating_point():
+            check_close(sd[k], ref, tol, "buffer " + k)
+        else:
+            assert torch.equal(sd[k].cpu(), ref), k
+    for k, ref in rec["params_after"].items():
+        check_close(sd[k], ref, 5 * tol, "param " + k)
+
+
+def assert_checksums(got, ref):
+    """(sum, abs-sum) per tensor; fp64 reductions may be re-associated across thread
+    counts, so compare to 1e-10 relative rather than bitwise."""
+    err = ((got - ref).abs() / (ref.abs() + 1e-9)).max()
+    assert float(err) < 1e-10, "constructor does not reproduce the reference's initial weights"

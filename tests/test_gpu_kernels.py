@@ -1,0 +1,389 @@
+"""Kernel-level parity: every HIP kernel (called through the C ABI via
+coclr_amd.ops) against the same op in plain fp32 PyTorch on the CPU.
+
+Tolerances: fp32 accumulation order differs from ATen's, so values are compared
+with max|delta| <= 2e-4 * max|ref| (well inside BASELINE.json's 1e-3); integer /
+index / mask outputs must match exactly.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-4
+
+
+def close(got, ref, rtol=RTOL, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale,
+                                                                            err / scale)
+
+
+def dev(t):
+    return t.cuda()
+
+
+def run_conv(x, w, stride, padding, accumulate_into=None, n_index=None, want_stats=True):
+    from coclr_amd import ops, engine
+    N = x.shape[0] if n_index is None else n_index.shape[0]
+    g = ops.ConvGeom(N, x.shape[1], w.shape[0], x.shape[2:], w.shape[2:], stride, padding)
+    run = engine.Run(torch.device("cuda"), save=False)
+    wd = dev(w)
+    packed = run.pack(wd, False)
+    y = torch.zeros(N, w.shape[0], *g.odim, device="cuda") if accumulate_into is None \
+        else dev(accumulate_into)
+    stats = torch.empty(2 * w.shape[0] * g.ntiles(), device="cuda") if want_stats else None
+    ops.conv_fwd(g, dev(x), packed, y, stats=stats,
+                 n_index=dev(n_index) if n_index is not None else None,
+                 accumulate=accumulate_into is not None)
+    torch.cuda.synchronize()
+    return g, y, stats
+
+
+CONV_CASES = [
+    # (N, Cin, Cout, (T,H,W), k, s, p)
+    (2, 3, 64, (8, 32, 32), (1, 7, 7), (1, 2, 2), (0, 3, 3)),      # stem spatial
+    (2, 64, 64, (8, 16, 16), (7, 1, 1), (2, 1, 1), (3, 0, 0)),     # stem temporal
+    (2, 64, 64, (4, 16, 16), (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # Conv_2b
+    (2, 64, 192, (4, 32, 32), (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # Conv_2c spatial
+    (2, 192, 192, (8, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0)),     # Conv_2c temporal
+    (3, 96, 208, (4, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # ragged Cout
+    (3, 208, 208, (4, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    (5, 480, 16, (2, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0)),      # tiny Cout, odd batch
+    (2, 16, 48, (2, 4, 4), (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # block5-like extent
+    (2, 48, 48, (2, 4, 4), (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    (2, 24, 64, (3, 7, 7), (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # non power-of-two extent
+    (2, 64, 64, (3, 7, 7), (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    (2, 832, 384, (2, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # Mixed_5c.branch0
+    (2, 128, 128, (4, 14, 14), (1, 3, 3), (1, 2, 2), (0, 1, 1)),   # r50 strided conv2
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "%d_%d_%d_%s_%s" % (c[0], c[1], c[2], c[3], c[4]))
+def test_conv_forward_and_stats(case):
+    N, Cin, Cout, dims, k, s, p = case
+    torch.manual_seed(0)
+    x = torch.randn(N, Cin, *dims)
+    w = torch.randn(Cout, Cin, *k) * 0.05
+    ref = F.conv3d(x, w, None, s, p)
+    g, y, stats = run_conv(x, w, s, p)
+    close(y, ref, what="conv y")
+    st = stats.view(2, Cout, -1).double().sum(-1).cpu()
+    close(st[0], ref.double().sum((0, 2, 3, 4)), rtol=1e-3, what="stats sum")
+    close(st[1], (ref.double() ** 2).sum((0, 2, 3, 4)), what="stats sumsq")
+
+
+@pytest.mark.parametrize("case", CONV_CASES[:13], ids=lambda c: "%d_%d_%d_%s_%s" % (c[0], c[1], c[2], c[3], c[4]))
+def test_conv_dgrad_wgrad(case):
+    from coclr_amd import ops, engine
+    N, Cin, Cout, dims, k, s, p = case
+    torch.manual_seed(1)
+    x = torch.randn(N, Cin, *dims, requires_grad=True)
+    w = (torch.randn(Cout, Cin, *k) * 0.05).requires_grad_(True)
+    ref = F.conv3d(x, w, None, s, p)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    g = ops.ConvGeom(N, Cin, Cout, dims, k, s, p)
+    run = engine.Run(torch.device("cuda"), save=False)
+    wd, dyd, xd = dev(w.detach()), dev(dy), dev(x.detach())
+    # data gradient, written then accumulated
+    dx = torch.empty(N, Cin, *dims, device="cuda")
+    ops.conv_fwd(g.dgrad(), dyd, run.pack(wd, True), dx)
+    close(dx, x.grad, what="dgrad")
+    ops.conv_fwd(g.dgrad(), dyd, run.pack(wd, True), dx, accumulate=True)
+    close(dx, 2 * x.grad, what="dgrad accumulate")
+    # weight gradient
+    dw = torch.empty_like(wd)
+    ws = torch.empty(g.wgrad_workspace(), device="cuda")
+    kk = k[0] * k[1] * k[2]
+    ops.conv_wgrad(g, xd, dyd, dw, ws, Cin * kk, kk, 0)
+    close(dw, w.grad, what="wgrad")
+
+
+def test_conv_channel_slices_gather_and_epilogue():
+    """x read from a wider buffer through n_index; y accumulated; fused affine+ReLU."""
+    from coclr_amd import ops, engine
+    torch.manual_seed(2)
+    big = torch.randn(6, 40, 4, 8, 8)
+    x = big[:, 8:24]
+    w = torch.randn(32, 16, 1, 3, 3) * 0.1
+    idx = torch.tensor([4, 0, 5, 2])
+    ref = F.conv3d(x[idx], w, None, 1, (0, 1, 1))
+    bigd = dev(big)
+    g, y, _ = run_conv(bigd[:, 8:24], w, (1, 1, 1), (0, 1, 1), n_index=idx)
+    close(y, ref, what="gathered slice conv")
+    base = torch.randn_like(ref)
+    g, y2, st = run_conv(bigd[:, 8:24], w, (1, 1, 1), (0, 1, 1), accumulate_into=base, n_index=idx)
+    close(y2, ref + base, what="accumulate")
+    close(st.view(2, 32, -1).sum(-1)[0], (ref + base).sum((0, 2, 3, 4)), rtol=1e-3, what="acc stats")
+    # epilogue: scale/shift/relu into a channel slice of a wider output
+    run = engine.Run(torch.device("cuda"), save=False)
+    out = torch.zeros(4, 50, 4, 8, 8, device="cuda")
+    sc, sh = torch.rand(32) + 0.5, torch.randn(32)
+    gg = ops.ConvGeom(4, 16, 32, (4, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    ops.conv_fwd(gg, bigd[:, 8:24], run.pack(dev(w), False), out[:, 10:42], ep_scale=dev(sc),
+                 ep_shift=dev(sh), n_index=dev(idx), relu=True)
+    exp = torch.relu(ref * sc[None, :, None, None, None] + sh[None, :, None, None, None])
+    close(out[:, 10:42], exp, what="epilogue")
+    assert out[:, :10].abs().max().item() == 0 and out[:, 42:].abs().max().item() == 0
+
+
+def test_sliced_stem_5x7x7():
+    """(5,7,7)/2 conv as five accumulated (1,7,7) launches + sliced wgrad (r50 stem)."""
+    from coclr_amd import ops, engine
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 8, 32, 32)
+    w = (torch.randn(64, 3, 5, 7, 7) * 0.05).requires_grad_(True)
+    ref = F.conv3d(x, w, None, (2, 2, 2), (2, 3, 3))
+    dyr = torch.randn_like(ref)
+    ref.backward(dyr)
+    run = engine.Run(torch.device("cuda"), save=False)
+    xd, wd, dyd = dev(x), dev(w.detach()), dev(dyr)
+    odim = tuple(ref.shape[2:])
+    y = torch.empty(2, 64, *odim, device="cuda")
+    dw = torch.zeros_like(wd)
+    for t in range(5):
+        g = ops.ConvGeom(2, 3, 64, x.shape[2:], (1, 7, 7), (2, 2, 2), (2 - t, 3, 3), odim=odim)
+        ops.conv_fwd(g, xd, run.pack(wd, False, t), y, accumulate=t > 0)
+        ws = torch.empty(g.wgrad_workspace(), device="cuda")
+        ops.conv_wgrad(g, xd, dyd, dw, ws, 3 * 245, 245, t * 49)
+    close(y, ref.detach(), what="sliced stem fwd")
+    close(dw, w.grad, what="sliced stem wgrad")
+
+
+@pytest.mark.parametrize("shape,relu,res", [((4, 24, 4, 8, 8), True, False),
+                                            ((3, 10, 3, 5, 7), True, True),
+                                            ((2, 64, 2, 4, 4), False, False)])
+def test_batchnorm_train_fwd_bwd(shape, relu, res):
+    from coclr_amd import ops
+    torch.manual_seed(4)
+    N, Cc = shape[0], shape[1]
+    y = (torch.randn(*shape) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(Cc) + 0.5).requires_grad_(True)
+    beta = torch.randn(Cc).requires_grad_(True)
+    rm, rv = torch.randn(Cc), torch.rand(Cc) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    resid = torch.randn(*shape).requires_grad_(True) if res else None
+    z = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        z = z + resid
+    if relu:
+        z = torch.relu(z)
+    dz = torch.randn_like(z)
+    z.backward(dz)
+
+    yd = dev(y.detach())
+    S = shape[2] * shape[3] * shape[4]
+    # statistics as the conv epilogue would deliver them: 3 partial tiles per channel
+    yy = y.detach().double().transpose(0, 1).reshape(Cc, -1)
+    chunks = torch.chunk(yy, 3, dim=1)
+    stats = torch.stack([torch.stack([c.sum(1) for c in chunks], 1),
+                         torch.stack([(c ** 2).sum(1) for c in chunks], 1)]).float()
+    small = torch.empty(4, Cc, device="cuda")
+    rmd, rvd = dev(rm0), dev(rv0)
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    ops.bn_finalize(dev(stats).contiguous(), Cc, 3, N * S, dev(gamma.detach()), dev(beta.detach()),
+                    rmd, rvd, nbt, 0.1, 1e-5, small[0], small[1], small[2], small[3])
+    close(rmd, rm, what="running_mean")
+    close(rvd, rv, what="running_var")
+    assert int(nbt) == 1
+    wide = torch.zeros(N, Cc + 6, *shape[2:], device="cuda")
+    zd = wide[:, 3:3 + Cc]
+    rd = dev(resid.detach()) if res else None
+    ops.bn_act_apply(yd, small[2], small[3], rd, zd, relu)
+    close(zd, z, what="bn apply")
+    # backward; dz lives in a channel slice too
+    dzw = torch.zeros(N, Cc + 6, *shape[2:], device="cuda")
+    dzw[:, 3:3 + Cc] = dev(dz)
+    dy = torch.empty_like(yd)
+    dgb = torch.empty(2, Cc, device="cuda")
+    dres = torch.full(shape, 1.0, device="cuda") if res else None
+    ops.bn_act_backward(dzw[:, 3:3 + Cc], yd, zd if res else None, small[2], small[3], small[0],
+                        small[1], torch.empty(2 * Cc, dtype=torch.float64, device="cuda"),
+                        torch.empty(3 * Cc, device="cuda"), dy, dres, dgb[0], dgb[1], relu, True,
+                        dres_accumulate=res)
+    close(dy, y.grad, rtol=5e-4, what="bn dy")
+    close(dgb[0], gamma.grad, rtol=5e-4, what="dgamma")
+    close(dgb[1], beta.grad, rtol=5e-4, what="dbeta")
+    if res:
+        close(dres, resid.grad + 1.0, what="dres accumulate")
+
+
+def test_batchnorm_eval_affine():
+    from coclr_amd import ops
+    torch.manual_seed(5)
+    Cc = 20
+    y = torch.randn(2, Cc, 2, 4, 4)
+    gamma, beta, rm, rv = torch.rand(Cc) + 0.5, torch.randn(Cc), torch.randn(Cc), torch.rand(Cc) + 0.5
+    ref = torch.relu(F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5))
+    small = torch.empty(4, Cc, device="cuda")
+    ops.bn_eval_affine(dev(gamma), dev(beta), dev(rm), dev(rv), 1e-5, Cc, small[0], small[1],
+                       small[2], small[3])
+    z = torch.empty(2, Cc, 2, 4, 4, device="cuda")
+    ops.bn_act_apply(dev(y), small[2], small[3], None, z, True)
+    close(z, ref, what="eval bn")
+
+
+POOLS = [((1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 5, 4, 16, 16)),
+         ((3, 3, 3), (2, 2, 2), (1, 1, 1), (2, 6, 8, 8, 8)),
+         ((2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 7, 4, 4, 4)),
+         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (3, 4, 4, 6, 5)),
+         ((1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 3, 2, 7, 7))]
+
+
+@pytest.mark.parametrize("k,s,p,shape", POOLS)
+def test_maxpool_fwd_bwd(k, s, p, shape):
+    from coclr_amd import ops
+    torch.manual_seed(6)
+    # post-ReLU-like input: many exact ties at 0 exercise first-max-wins
+    x = torch.relu(torch.randn(*shape)).requires_grad_(True)
+    ref, ridx = F.max_pool3d(x, k, s, p, return_indices=True)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    g = ops.PoolGeom(shape[0], shape[1], shape[2:], k, s, p)
+    y = torch.empty(shape[0], shape[1], *g.odim, device="cuda")
+    idx = torch.empty(shape[0], shape[1], *g.odim, dtype=torch.int32, device="cuda")
+    ops.maxpool_fwd(g, dev(x.detach()), y, idx)
+    assert torch.equal(y.cpu(), ref.detach()), "maxpool values must be exact"
+    assert torch.equal(idx.cpu().long(), ridx), "argmax must match ATen's first-max-wins"
+    dx = torch.full(shape, 0.5, device="cuda")
+    ops.maxpool_bwd(g, dev(dy), idx, dx, accumulate=True)
+    close(dx, x.grad + 0.5, what="maxpool bwd accumulate")
+    ops.maxpool_bwd(g, dev(dy), idx, dx, accumulate=False)
+    close(dx, x.grad, what="maxpool bwd")
+
+
+def test_global_avgpool():
+    from coclr_amd import ops
+    x = torch.randn(3, 10, 2, 4, 4)
+    y = torch.empty(3, 10, 1, 1, 1, device="cuda")
+    ops.global_avgpool_fwd(dev(x), y)
+    close(y, x.mean((2, 3, 4), keepdim=True), what="avgpool")
+    dy = torch.randn(3, 10, 1, 1, 1)
+    dx = torch.empty(3, 10, 2, 4, 4, device="cuda")
+    ops.global_avgpool_bwd(dev(dy), dx)
+    close(dx, (dy / 32).expand(3, 10, 2, 4, 4), what="avgpool bwd")
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,splits", [(32, 1024, 1024, False, True, 1),
+                                               (4, 128, 1000, False, False, 1),
+                                               (37, 200, 70, True, False, 1),
+                                               (33, 130, 515, True, True, 4),
+                                               (32, 128, 16384, False, True, 128)])
+def test_gemm_layouts(M, N, K, ta, tb, splits):
+    from coclr_amd import ops
+    torch.manual_seed(7)
+    A = torch.randn(K, M).t() if ta else torch.randn(M, K)      # logical (M,K)
+    Bm = torch.randn(N, K).t() if tb else torch.randn(K, N)     # logical (K,N)
+    bias = torch.randn(N)
+    ref = torch.relu(0.5 * (A.double() @ Bm.double()).float() + bias)
+    Ad = dev(A.t().contiguous()).t() if ta else dev(A.contiguous())
+    Bd = dev(Bm.t().contiguous()).t() if tb else dev(Bm.contiguous())
+    c = torch.empty(M, N, device="cuda")
+    ws = torch.empty(max(1, ops.gemm_workspace(M, N, K, splits)), device="cuda")
+    ops.gemm(Ad, Ad.stride(0), Ad.stride(1), Bd, Bd.stride(0), Bd.stride(1), c, N, dev(bias), M, N,
+             K, alpha=0.5, relu=True, splits=splits, workspace=ws)
+    close(c, ref, what="gemm")
+
+
+def test_l2norm_and_logits():
+    from coclr_amd import ops
+    torch.manual_seed(8)
+    B, D, K, T = 6, 128, 640, 0.07
+    x = torch.randn(B, D, requires_grad=True)
+    q = F.normalize(x, dim=1)
+    k = F.normalize(torch.randn(B, D), dim=1)
+    queue = F.normalize(torch.randn(D, K), dim=0)
+    logits = torch.cat([torch.einsum('nc,nc->n', [q, k]).unsqueeze(-1),
+                        torch.einsum('nc,ck->nk', [q, queue])], 1) / T
+    dl = torch.randn_like(logits)
+    logits.backward(dl)
+
+    xd = dev(x.detach())
+    qd, inv = torch.empty_like(xd), torch.empty(B, device="cuda")
+    ops.l2norm_fwd(xd, qd, inv)
+    close(qd, q, what="normalize")
+    lg = torch.empty(B, 1 + K, device="cuda")
+    ops.nce_logits_fwd(qd, dev(k), dev(queue), lg, T)
+    close(lg, logits, what="logits")
+    dq = torch.empty(B, D, device="cuda")
+    splits = 5
+    ws = torch.empty(ops.gemm_workspace(B, D, K, splits), device="cuda")
+    ops.nce_logits_bwd(dev(dl), dev(k), dev(queue), dq, ws, T, splits)
+    dx = torch.empty_like(xd)
+    ops.l2norm_bwd(dq, qd, inv, dx)
+    close(dx, x.grad, rtol=5e-4, what="normalize+logits bwd")
+
+
+def test_momentum_enqueue_mask_gather():
+    from coclr_amd import ops
+    torch.manual_seed(9)
+    # momentum over two tensors, one spanning several chunks
+    pk = [torch.randn(70000), torch.randn(33)]
+    pq = [torch.randn(70000), torch.randn(33)]
+    pkd, pqd = [dev(t) for t in pk], [dev(t) for t in pq]
+    rows = []
+    for a, b in zip(pkd, pqd):
+        for off in range(0, a.numel(), 32768):
+            rows.append((a.data_ptr() + 4 * off, b.data_ptr() + 4 * off, min(32768, a.numel() - off)))
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    m = 0.999
+    ops.momentum_update(table, len(rows), float(m), float(1. - m))
+    for a, b, c in zip(pkd, pk, pq):
+        assert torch.equal(a.cpu(), b * m + c * (1. - m)), "momentum must be bit-exact"
+
+    # enqueue with wrap-around
+    D, K, BW = 16, 12, 4
+    queue = torch.randn(D, K)
+    qd = dev(queue)
+    ptr = torch.tensor([8], dtype=torch.long).cuda()
+    keys = torch.randn(BW, D)
+    lab = torch.full((K,), -1, dtype=torch.long).cuda()
+    ops.queue_enqueue(qd, dev(keys), ptr)
+    ops.queue_fill_i64(lab, torch.arange(BW).cuda(), 0, BW, ptr)
+    ops.queue_advance(ptr, BW, K)
+    queue[:, 8:12] = keys.T
+    assert torch.equal(qd.cpu(), queue) and int(ptr) == 0
+    assert lab.cpu().tolist() == [-1] * 8 + [0, 1, 2, 3]
+    ops.queue_fill_i64(lab, None, 1, BW, ptr)
+    assert lab.cpu().tolist()[:4] == [1, 1, 1, 1]
+
+    # positive mask + top-k mining
+    B, K = 5, 300
+    sim = torch.randn(B, K)
+    src = torch.randint(0, 4, (B,))
+    names = torch.randint(0, 4, (K,))
+    names[:7] = -1
+    mask_source = src[:, None] == names[None, :]
+    ms = sim.clone()
+    ms[mask_source] = -float("inf")
+    _, idx = torch.topk(ms, 5, dim=1)
+    exp = mask_source.clone()
+    exp.scatter_(1, idx, True)
+    exp = torch.cat([torch.ones(B, 1, dtype=torch.bool), exp], 1)
+    mask = torch.empty(B, 1 + K, dtype=torch.uint8, device="cuda")
+    ops.positive_mask(dev(sim), dev(src), dev(names), mask, 5)
+    assert torch.equal(mask.cpu().bool(), exp)
+    ops.positive_mask(None, dev(src), dev(names), mask, 0)
+    assert torch.equal(mask.cpu().bool()[:, 1:], mask_source)
+
+    # row gather
+    x = torch.randn(6, 3, 4, 5)
+    idx = torch.tensor([5, 0, 3])
+    out = torch.empty(3, 3, 4, 5, device="cuda")
+    ops.gather_rows(dev(x), dev(idx), out)
+    assert torch.equal(out.cpu(), x[idx])
+
+    # relu + colsum
+    y = torch.empty(6, 60, device="cuda")
+    xr = torch.randn(6, 60)
+    ops.relu_fwd(dev(xr), y)
+    assert torch.equal(y.cpu(), torch.relu(xr))
+    cs = torch.empty(60, device="cuda")
+    ops.colsum(dev(xr), cs)
+    close(cs, xr.sum(0), what="colsum")

@@ -1,0 +1,120 @@
+"""End-to-end parity on the MI355X: the product classes (model.pretrain.* on the HIP
+kernel library) replay the recorded reference runs in tests/golden/ -- same seeds,
+same inputs, two optimisation steps -- and must agree within BASELINE.json's 1e-3
+relative tolerance on logits, loss and queue state (gradients: 5e-3 of the tensor's
+max, they pass through ~80 fp32 layers)."""
+import pytest
+import torch
+
+from _cases import (assert_checksums, build_model, case_inputs, compare_state, compare_step, load_golden, loss_fn)
+
+pytestmark = pytest.mark.gpu
+
+
+def _ensure_pg():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29611")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+
+
+def _replay(name, with_pg=False):
+    import model.pretrain as product
+    gold = load_golden(name)
+    cfg = gold["cfg"]
+    kind = cfg["kind"]
+    if with_pg:
+        _ensure_pg()
+    model = build_model(cfg, product)
+    # identical initial weights as the reference from the same seed
+    sd = model.state_dict()
+    keys = gold["init_checksums"]["keys"]
+    from _cases import checksum_table
+    assert_checksums(checksum_table(sd, keys), gold["init_checksums"]["vals"])
+    model = model.cuda()
+    params = [{"params": p} for _, p in model.named_parameters()]
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-5)
+    model.train()
+    if kind == "coclr":
+        model.sampler.eval()
+    for step, rec in enumerate(gold["steps"]):
+        blocks, extra = case_inputs(cfg, step)
+        torch.manual_seed(cfg["perm_seed"] + step)
+        if kind == "infonce":
+            out, tgt = model(blocks[0].cuda())
+        elif kind == "ubernce":
+            out, tgt = model(blocks[0].cuda(), extra.cuda())
+        else:
+            out, tgt = model(blocks[0].cuda(), blocks[1].cuda(), extra.cuda())
+        loss = loss_fn(kind, out, tgt)
+        opt.zero_grad()
+        loss.backward()
+        grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        compare_step(rec, kind, out, tgt, loss, grads)
+        opt.step()
+        compare_state(rec, model.state_dict(), cfg["B"], cfg["K"])
+
+
+@pytest.mark.parametrize("name", ["infonce_s3d_small", "ubernce_s3d_small", "coclr_s3d_small",
+                                  "coclr_s3d_small_reverse_cold", "infonce_s3dg_small"])
+def test_small_cases_match_reference(name):
+    _replay(name)
+
+
+def test_r50_matches_reference():
+    _replay("infonce_r50_small")
+
+
+def test_config1_matches_reference():
+    """BASELINE.json configs[0]: S3D InfoNCE K=2048 B=4 on 3x32x128x128 clips."""
+    _replay("infonce_s3d_config1")
+
+
+def test_single_rank_process_group_path():
+    """Same numbers when a 1-rank RCCL process group is initialised (the way
+    main_nce.py runs it on one GPU)."""
+    _replay("infonce_s3d_small", with_pg=True)
+
+
+def test_no_grad_forward_leaves_state_untouched():
+    import model.pretrain as product
+    gold = load_golden("infonce_s3d_small")
+    cfg = gold["cfg"]
+    model = build_model(cfg, product).cuda().train()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    blocks, _ = case_inputs(cfg, 0)
+    torch.manual_seed(cfg["perm_seed"])
+    with torch.no_grad():
+        out, _ = model(blocks[0].cuda())
+    after = model.state_dict()
+    # in_train_mode is False: no momentum update, no enqueue (model/pretrain.py:157,161,188)
+    for k in ("queue", "queue_ptr", "encoder_k.4.bias", "encoder_k.0.Conv_1a.conv1.weight"):
+        assert torch.equal(before[k], after[k]), k
+    from _cases import check_close
+    check_close(out, gold["steps"][0]["logits"], 1e-3, "no-grad logits")
+
+
+def test_k_not_multiple_of_batch_asserts():
+    import model.pretrain as product
+    torch.manual_seed(0)
+    model = product.InfoNCE('s3d', 128, 30, 0.999, 0.07).cuda().train()
+    x = torch.randn(4, 2, 3, 16, 64, 64).cuda()
+    with pytest.raises(AssertionError):
+        model(x)
+    with pytest.raises(AssertionError):
+        model(torch.randn(4, 3, 3, 16, 64, 64).cuda())   # N != 2
+
+
+def test_select_backbone_contract():
+    from backbone.select_backbone import select_backbone
+    net, param = select_backbone('s3d')
+    assert param == {'feature_size': 1024}
+    _, param = select_backbone('r50')
+    assert param == {'feature_size': 2048}
+    with pytest.raises(NotImplementedError):
+        select_backbone('vgg')
+    x = torch.randn(2, 3, 16, 64, 64).cuda()
+    y = net.cuda()(x)
+    assert y.shape == (2, 1024, 2, 2, 2)
