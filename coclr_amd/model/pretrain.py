@@ -248,7 +248,9 @@ class InfoNCE(nn.Module):
         if self._momentum_table is None or self._momentum_table[0] != sig:
             self._build_momentum_table()
         _, table, n = self._momentum_table
-        ops.momentum_update(table, n, float(self.m), float(1. - self.m))
+        pairs = [(pk.data, pq.data) for pq, pk in zip(self.encoder_q.parameters(),
+                                                      self.encoder_k.parameters())]
+        ops.momentum_update(table, n, float(self.m), float(1. - self.m), pairs=pairs)
 
     # -- queue ---------------------------------------------------------------------
     @torch.no_grad()

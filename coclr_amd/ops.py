@@ -258,7 +258,9 @@ def nce_logits_bwd(dlogits, k, queue, dq, workspace, T, splits):
                "nce_logits_bwd")
 
 
-def momentum_update(table, nchunks, m, one_minus_m):
+def momentum_update(table, nchunks, m, one_minus_m, pairs=None):
+    """`pairs` (the (dst, src) tensors the pointer table was built from) is not used by the
+    kernel; callers pass it so the tensors stay referenced while the launch is queued."""
     _lib.check(_lib.load().coclr_momentum_update(_p(table, torch.int64), nchunks, m, one_minus_m,
                                                  _stream()), "momentum_update")
 

@@ -1,0 +1,293 @@
+"""TEST DOUBLE for coclr_amd.ops: every kernel entry point re-expressed with ATen CPU ops
+on the same buffers/layouts (packed weights, [2][C][ntiles] statistics, channel-slice
+views, int32 pool indices, device-side queue pointer).
+
+It exists so the HOST logic -- the engine's tape, concat-free inception wiring, gradient
+accumulation, the InfoNCE/UberNCE/CoCLR step sequencing and the gloo/world-size-2
+collectives -- can be exercised in the CPU-only test tier.  It is installed only by
+tests (`install(monkeypatch)`); the product has no CPU path and never imports this file.
+"""
+import torch
+import torch.nn.functional as F
+
+from coclr_amd import ops
+
+
+def _r32(v):
+    return (v + 31) // 32 * 32
+
+
+def conv_packed_size(cin, cout, taps, transpose):
+    r, c = (cout, cin) if transpose else (cin, cout)
+    return taps * _r32(r) * _r32(c)
+
+
+def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose):
+    w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, taps), (co_stride, ci_stride, 1),
+                          tap_base)
+    r, c = (cout, cin) if transpose else (cin, cout)
+    dst = packed.view(taps, _r32(r), _r32(c))
+    dst.zero_()
+    if transpose:
+        dst[:, :cout, :cin] = w3.flip(2).permute(2, 0, 1)
+    else:
+        dst[:, :cin, :cout] = w3.permute(2, 1, 0)
+
+
+def _unpack(geom, wp):
+    taps = geom.taps
+    w = wp.view(taps, _r32(geom.Cin), _r32(geom.Cout))[:, :geom.Cin, :geom.Cout]
+    return w.permute(2, 1, 0).reshape(geom.Cout, geom.Cin, *geom.k).contiguous()
+
+
+def _virtual_input(geom, x, n_index):
+    xs = x if n_index is None else x[n_index]
+    xs = xs[:geom.N]
+    d = geom.d
+    if d != (1, 1, 1):
+        T, H, W = xs.shape[2:]
+        up = xs.new_zeros(xs.shape[0], xs.shape[1], (T - 1) * d[0] + 1, (H - 1) * d[1] + 1,
+                          (W - 1) * d[2] + 1)
+        up[:, :, ::d[0], ::d[1], ::d[2]] = xs
+        xs = up
+    return xs
+
+
+def _conv_raw(geom, xs, w):
+    """conv with possibly negative padding, output cropped / zero-extended to geom.odim."""
+    pad = list(geom.p)
+    sl = [slice(None)] * 3
+    for i in range(3):
+        if pad[i] < 0:
+            sl[i] = slice(-pad[i], None)
+            pad[i] = 0
+    xs = xs[:, :, sl[0], sl[1], sl[2]]
+    # make sure every requested output position exists: extend the input with zeros at the end
+    need = [(geom.odim[i] - 1) * geom.s[i] + geom.k[i] - 2 * pad[i] for i in range(3)]
+    extra = [max(0, need[i] - xs.shape[2 + i]) for i in range(3)]
+    if any(extra):
+        xs = F.pad(xs, (0, extra[2], 0, extra[1], 0, extra[0]))
+    out = F.conv3d(xs, w, None, geom.s, tuple(pad))
+    return out[:, :, :geom.odim[0], :geom.odim[1], :geom.odim[2]]
+
+
+def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shift=None,
+             n_index=None, relu=False, accumulate=False):
+    w = _unpack(geom, w_packed)
+    raw = _conv_raw(geom, _virtual_input(geom, x, n_index), w)
+    if accumulate:
+        raw = raw + y
+    if stats is not None:
+        st = stats.view(2, geom.Cout, geom.ntiles())
+        st.zero_()
+        st[0, :, 0] = raw.sum((0, 2, 3, 4))
+        st[1, :, 0] = (raw * raw).sum((0, 2, 3, 4))
+    v = raw
+    if bias is not None:
+        v = v + bias.view(1, -1, 1, 1, 1)
+    if ep_scale is not None:
+        v = v * ep_scale.view(1, -1, 1, 1, 1) + ep_shift.view(1, -1, 1, 1, 1)
+    if relu:
+        v = torch.relu(v)
+    y.copy_(v)
+
+
+def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accumulate=False):
+    w0 = torch.zeros(geom.Cout, geom.Cin, *geom.k, requires_grad=True)
+    with torch.enable_grad():
+        out = _conv_raw(geom, _virtual_input(geom, x.detach(), None), w0)
+        out.backward(dy.detach()[:geom.N])
+    dst = torch.as_strided(dw.reshape(-1), (geom.Cout, geom.Cin, geom.taps),
+                           (co_stride, ci_stride, 1), tap_base)
+    g = w0.grad.reshape(geom.Cout, geom.Cin, geom.taps)
+    if accumulate:
+        dst.add_(g)
+    else:
+        dst.copy_(g)
+
+
+def bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt, momentum,
+                eps, mean, invstd, scale, shift):
+    st = stats.view(2, C_, ntiles).double().sum(-1)
+    mu = st[0] / count
+    var = (st[1] / count - mu * mu).clamp_min(0)
+    inv = 1.0 / torch.sqrt(var + eps)
+    mean.copy_(mu.float())
+    invstd.copy_(inv.float())
+    scale.copy_(gamma * invstd)
+    shift.copy_(beta - mean * scale)
+    if running_mean is not None:
+        unb = var * count / (count - 1) if count > 1 else var
+        running_mean.mul_(1 - momentum).add_(momentum * mu.float())
+        running_var.mul_(1 - momentum).add_(momentum * unb.float())
+    if nbt is not None:
+        nbt += 1
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps, C_, mean, invstd, scale, shift):
+    mean.copy_(running_mean)
+    invstd.copy_(1.0 / torch.sqrt(running_var + eps))
+    scale.copy_(gamma * invstd)
+    shift.copy_(beta - running_mean * scale)
+
+
+def _b(v):
+    return v.view(1, -1, 1, 1, 1)
+
+
+def bn_act_apply(y, scale, shift, residual, z, relu):
+    v = y * _b(scale) + _b(shift)
+    if residual is not None:
+        v = v + residual
+    z.copy_(torch.relu(v) if relu else v)
+
+
+def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, coef_ws, dy, dres, dgamma,
+                    dbeta, relu, training, dres_accumulate=False):
+    g = dz
+    if relu:
+        mask = (z > 0) if z is not None else ((y * _b(scale) + _b(shift)) > 0)
+        g = dz * mask
+    xhat = (y - _b(mean)) * _b(invstd)
+    sg = g.double().sum((0, 2, 3, 4))
+    sgx = (g.double() * xhat.double()).sum((0, 2, 3, 4))
+    if dgamma is not None:
+        dgamma.copy_(sgx.float())
+    if dbeta is not None:
+        dbeta.copy_(sg.float())
+    if dres is not None:
+        if dres_accumulate:
+            dres.add_(g)
+        else:
+            dres.copy_(g)
+    if training:
+        cnt = y.numel() / y.shape[1]
+        dy.copy_(_b(scale) * (g - _b((sg / cnt).float()) - xhat * _b((sgx / cnt).float())))
+    else:
+        dy.copy_(_b(scale) * g)
+
+
+def maxpool_fwd(geom, x, y, indices=None):
+    out, idx = F.max_pool3d(x, geom.k, geom.s, geom.p, return_indices=True)
+    y.copy_(out)
+    if indices is not None:
+        indices.copy_(idx.to(torch.int32))
+
+
+def maxpool_bwd(geom, dy, indices, dx, accumulate=False):
+    N, Cc = dx.shape[:2]
+    flat = torch.zeros(N, Cc, dx.shape[2] * dx.shape[3] * dx.shape[4])
+    flat.scatter_add_(2, indices.reshape(N, Cc, -1).long(), dy.reshape(N, Cc, -1))
+    g = flat.view(N, Cc, *dx.shape[2:])
+    if accumulate:
+        dx.add_(g)
+    else:
+        dx.copy_(g)
+
+
+def global_avgpool_fwd(x, y):
+    y.copy_(x.mean((2, 3, 4), keepdim=True))
+
+
+def global_avgpool_bwd(dy, dx):
+    S = dx.shape[2] * dx.shape[3] * dx.shape[4]
+    dx.copy_((dy / S).expand_as(dx))
+
+
+def gemm_workspace(M, N, K, splits):
+    return M * N * splits if splits > 1 else 0
+
+
+def gemm(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha=1.0, relu=False, accumulate=False,
+         splits=1, workspace=None):
+    A = torch.as_strided(a, (M, K), (sam, sak))
+    Bm = torch.as_strided(b, (K, N), (sbk, sbn))
+    v = alpha * (A @ Bm)
+    if bias is not None:
+        v = v + bias
+    if relu:
+        v = torch.relu(v)
+    dst = torch.as_strided(c, (M, N), (ldc, 1))
+    if accumulate:
+        dst.add_(v)
+    else:
+        dst.copy_(v)
+
+
+def l2norm_fwd(x, y, inv_norm, eps=1e-12):
+    inv = 1.0 / x.norm(dim=1).clamp_min(eps)
+    y.copy_(x * inv[:, None])
+    if inv_norm is not None:
+        inv_norm.copy_(inv)
+
+
+def l2norm_bwd(dy, y, inv_norm, dx):
+    dot = (dy * y).sum(1, keepdim=True)
+    dx.copy_((dy - y * dot) * inv_norm[:, None])
+
+
+def nce_logits_fwd(q, k, queue, logits, T):
+    logits[:, 0] = (q * k).sum(1) / T
+    logits[:, 1:] = (q @ queue) / T
+
+
+def nce_logits_bwd(dlogits, k, queue, dq, workspace, T, splits):
+    dq.copy_((dlogits[:, 1:] @ queue.t() + dlogits[:, :1] * k) / T)
+
+
+def momentum_update(table, nchunks, m, one_minus_m, pairs=None):
+    mf = torch.tensor(m, dtype=torch.float32)
+    of = torch.tensor(one_minus_m, dtype=torch.float32)
+    for dst, src in pairs:
+        dst.copy_(dst * mf + src * of)
+
+
+def queue_enqueue(queue, keys, ptr):
+    p = int(ptr)
+    queue[:, p:p + keys.shape[0]] = keys.t()
+
+
+def queue_fill_i64(queue, vals, const_val, BW, ptr):
+    p = int(ptr)
+    queue[p:p + BW] = vals if vals is not None else const_val
+
+
+def queue_advance(ptr, BW, K):
+    ptr[0] = (int(ptr) + BW) % K
+
+
+def positive_mask(sim, src, names, mask, topk):
+    same = src[:, None] == names[None, :]
+    m = same.clone()
+    if topk > 0:
+        s = sim.clone()
+        s[same] = -float("inf")
+        _, idx = torch.topk(s, topk, dim=1)
+        m.scatter_(1, idx, True)
+    mask[:, 0] = 1
+    mask[:, 1:] = m.to(mask.dtype)
+
+
+def gather_rows(inp, idx, out):
+    out.copy_(inp[idx])
+
+
+def relu_fwd(x, y):
+    y.copy_(torch.relu(x))
+
+
+def relu_bwd(dy, y, dx):
+    dx.copy_(dy * (y > 0))
+
+
+def colsum(x, out):
+    out.copy_(x.sum(0))
+
+
+_NAMES = [n for n, v in list(globals().items())
+          if callable(v) and not n.startswith("_") and hasattr(ops, n) and n not in ("F",)]
+
+
+def install(monkeypatch):
+    for n in _NAMES:
+        monkeypatch.setattr(ops, n, globals()[n])
