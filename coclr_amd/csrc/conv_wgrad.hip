@@ -19,11 +19,12 @@
 
 namespace {
 
+__device__ float g_zero[64];   // zero-initialised; source for masked lanes of the LDS DMA
+
 struct WgradArgs {
   const float* x;
   const float* dy;
   float* part;            // [S][Cout][J]
-  const int64_t* n_index; // optional gather of x samples (unused by callers today)
   long x_nstride, dy_nstride;
   int x_cstride, dy_cstride;
   int N, Cin, Cout, J, taps, KH, KW;
@@ -31,27 +32,30 @@ struct WgradArgs {
   int st, sh, sw, pt, ph, pw;
   int lTW, lTH, lTT, lTN;
   int nbw, nbh, nbt, nbn;
-  int WT, WH, WW, plane1, plane, planeP;
+  int WT, WH, WW, plane1, plane, planeP, pch;
   int ntiles, S, jtiles, mtiles;
 };
 
+#define GLDS4(gptr, lptr)                                                                   \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),   \
+                                   (__attribute__((address_space(3))) void*)(lptr), 4, 0, 0)
+
 // BM = 64 couts, BN = 128 positions per staged box, BJ = j extent of the tile,
-// NCI = max channels staged, PT/PI as in the forward kernel.
-template <int BJ, int NCI, int PT, int PI>
+// PCH = max number of 64-element chunks of one channel's window.
+// Staging is done entirely by the LDS DMA engine (global_load_lds_dword): no staging
+// registers, every load of a tile in flight at once; masked elements read g_zero.
+template <int BJ, int PCH>
 __global__ void __launch_bounds__(256)
 conv_wgrad_kernel(const WgradArgs a) {
   constexpr int BM = 64, BN = 128;
-  constexpr int WM = 2, WN = 2;
+  constexpr int WN = 2;
   constexpr int NF = BJ / (WN * 32);
-  constexpr int CG = 256 / PT;
-  constexpr int CI = (NCI + CG - 1) / CG;
-  constexpr int DYI = BM * BN / 256;   // dY elements per thread per box
   constexpr int LDY = BN + 1;
 
   extern __shared__ __align__(16) float smem[];
-  float* dYs = smem;                       // [BM][LDY]
-  int* pwoff = reinterpret_cast<int*>(smem + BM * LDY);  // [BN]
-  float* Xs = smem + BM * LDY + BN;        // [NCI][planeP]
+  float* dYs = smem;                                      // [BM][LDY]
+  int* pwoff = reinterpret_cast<int*>(smem + BM * LDY);   // [BN]
+  float* Xs = smem + BM * LDY + BN;                       // [nci][planeP]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -59,21 +63,21 @@ conv_wgrad_kernel(const WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
 
   const int split = blockIdx.x;
-  const int jt = blockIdx.y, mt = blockIdx.z;
-  const int j0 = jt * BJ, cout0 = mt * BM;
+  const int j0 = blockIdx.y * BJ, cout0 = blockIdx.z * BM;
   const int cin_lo = j0 / a.taps;
   int cin_hi = (j0 + BJ - 1) / a.taps;      // inclusive
   if (cin_hi >= a.Cin) cin_hi = a.Cin - 1;
   const int nci = cin_hi - cin_lo + 1;
-  const int plane = a.plane, planeP = a.planeP;
+  const int planeP = a.planeP;
+  const int lW = a.lTW, lWH = a.lTW + a.lTH, lWHT = a.lTW + a.lTH + a.lTT;
 
   // box-position -> window offset table
   if (tid < BN) {
     const int p = tid;
-    const int tw = p & ((1 << a.lTW) - 1);
-    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
-    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
-    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    const int tw = p & ((1 << lW) - 1);
+    const int th = (p >> lW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> lWH) & ((1 << a.lTT) - 1);
+    const int tn = p >> lWHT;
     pwoff[p] = tn * a.plane1 + ((tt * a.st) * a.WH + th * a.sh) * a.WW + tw * a.sw;
   }
 
@@ -94,91 +98,79 @@ conv_wgrad_kernel(const WgradArgs a) {
   }
   const int abase = (wm * 32 + l31) * LDY;
 
+  // tile-independent decode of this lane's window elements: packed (wn, wt, wh, ww)
+  unsigned wcoord[PCH];
+#pragma unroll
+  for (int ch = 0; ch < PCH; ++ch) {
+    const int e = ch * 64 + lane;
+    unsigned v = 0xffffffffu;
+    if (e < a.plane) {
+      const int wn_ = e / a.plane1;
+      int q = e - wn_ * a.plane1;
+      const int hw = a.WH * a.WW;
+      const int wt = q / hw; q -= wt * hw;
+      const int wh = q / a.WW;
+      const int ww = q - wh * a.WW;
+      v = (unsigned)wn_ | ((unsigned)wt << 8) | ((unsigned)wh << 16) | ((unsigned)ww << 24);
+    }
+    wcoord[ch] = v;
+  }
+
   f32x16 acc[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
 
-  const int pe = tid % PT, cg = tid / PT;
-  const int pdy = tid & (BN - 1), mdy = tid >> 7;  // dY staging: position, row parity
-
-  float xr[CI][PI];
-  float dyr[DYI];
-
-  auto load_tile = [&](int tile) {
+  for (int tile = split; tile < a.ntiles; tile += a.S) {
     int r = tile;
     const int bw_ = r % a.nbw; r /= a.nbw;
     const int bh_ = r % a.nbh; r /= a.nbh;
     const int bt_ = r % a.nbt; r /= a.nbt;
     const int n0 = r << a.lTN;
-    const int ow0 = bw_ << a.lTW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;
-    // dY
-    {
-      const int p = pdy;
-      const int tw = p & ((1 << a.lTW) - 1);
-      const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
-      const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
-      const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    const int ow0 = bw_ << lW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;
+
+    __syncthreads();     // previous tile fully consumed (also orders pwoff on the first pass)
+
+    // ---- dY: rows wave, wave+4, ... ; two 64-position halves per row ----------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = h * 64 + lane;
+      const int tw = p & ((1 << lW) - 1);
+      const int th = (p >> lW) & ((1 << a.lTH) - 1);
+      const int tt = (p >> lWH) & ((1 << a.lTT) - 1);
+      const int tn = p >> lWHT;
       const int n = n0 + tn, ot = ot0 + tt, oh = oh0 + th, ow = ow0 + tw;
       const bool ok = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
-      const long off = (long)n * a.dy_nstride + ((long)ot * a.Ho + oh) * a.Wo + ow;
-#pragma unroll
-      for (int i = 0; i < DYI; ++i) {
-        const int co = cout0 + mdy + 2 * i;
-        dyr[i] = (ok && co < a.Cout) ? a.dy[off + (long)co * a.dy_cstride] : 0.f;
+      const float* base = a.dy + (long)n * a.dy_nstride + ((long)ot * a.Ho + oh) * a.Wo + ow;
+      for (int row = wave; row < BM; row += 4) {
+        const int co = cout0 + row;
+        const float* src = (ok && co < a.Cout) ? base + (long)co * a.dy_cstride : g_zero;
+        GLDS4(src, dYs + row * LDY + h * 64);
       }
     }
-    // X window
+    // ---- X window: channels wave, wave+4, ... ----------------------------------------
     const int vt0 = ot0 * a.st - a.pt, vh0 = oh0 * a.sh - a.ph, vw0 = ow0 * a.sw - a.pw;
 #pragma unroll
-    for (int i = 0; i < PI; ++i) {
-      const int e = pe + i * PT;
-      long g = -1;
-      if (e < plane) {
-        const int wn_ = e / a.plane1;
-        int q = e - wn_ * a.plane1;
-        const int hw = a.WH * a.WW;
-        const int wt = q / hw; q -= wt * hw;
-        const int wh = q / a.WW;
-        const int ww = q - wh * a.WW;
-        const int n = n0 + wn_;
-        const int it = vt0 + wt, ih = vh0 + wh, iw = vw0 + ww;
-        if (n < a.N && it >= 0 && ih >= 0 && iw >= 0 && it < a.Ti && ih < a.Hi && iw < a.Wi) {
-          const long ns = a.n_index ? (long)a.n_index[n] : (long)n;
-          g = ns * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw;
-        }
-      }
-#pragma unroll
-      for (int ci = 0; ci < CI; ++ci) {
-        const int c = ci * CG + cg;
-        xr[ci][i] = (g >= 0 && c < nci) ? a.x[g + (long)(cin_lo + c) * a.x_cstride] : 0.f;
-      }
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < DYI; ++i) dYs[(mdy + 2 * i) * LDY + pdy] = dyr[i];
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci) {
-      const int c = ci * CG + cg;
-      if (c < NCI) {
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-          const int e = pe + i * PT;
-          if (e < plane) Xs[c * planeP + e] = xr[ci][i];
+    for (int ch = 0; ch < PCH; ++ch) {
+      if (ch < a.pch) {
+        const unsigned wc = wcoord[ch];
+        const int n = n0 + (int)(wc & 255u);
+        const int it = vt0 + (int)((wc >> 8) & 255u);
+        const int ih = vh0 + (int)((wc >> 16) & 255u);
+        const int iw = vw0 + (int)(wc >> 24);
+        const bool ok = wc != 0xffffffffu && n < a.N && it >= 0 && ih >= 0 && iw >= 0 &&
+                        it < a.Ti && ih < a.Hi && iw < a.Wi;
+        const float* base = a.x + (long)n * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw +
+                            (long)cin_lo * a.x_cstride;
+        for (int c = wave; c < nci; c += 4) {
+          const float* src = ok ? base + (long)c * a.x_cstride : g_zero;
+          GLDS4(src, Xs + c * planeP + ch * 64);
         }
       }
     }
-  };
+    __syncthreads();     // drains the DMA queue (vmcnt(0)) and publishes the tile
 
-  int tile = split;
-  if (tile < a.ntiles) load_tile(tile);
-  for (; tile < a.ntiles; tile += a.S) {
-    __syncthreads();
-    store_tile();
-    __syncthreads();
-    if (tile + a.S < a.ntiles) load_tile(tile + a.S);
 #pragma unroll 8
     for (int s = 0; s < BN / 2; ++s) {
       const int p = 2 * s + half;
@@ -229,7 +221,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 
 struct WPlan {
   ConvPlan p;
-  int variant, BJ, S, jtiles, mtiles, planeP;
+  int variant, BJ, S, jtiles, mtiles, planeP, pch, nci_max;
 };
 
 int plan_wgrad(const coclr_conv_desc* d, WPlan* w) {
@@ -240,44 +232,35 @@ int plan_wgrad(const coclr_conv_desc* d, WPlan* w) {
   const int taps = d->kt * d->kh * d->kw;
   conv_pick_box(&p, 7, d->kt, d->kh, d->kw);
   const int J = p.Cin * taps;
-  // variant table: (BJ, NCI, PT, PI)
-  if (taps == 1) {
-    if (p.plane <= 128) { w->variant = 0; w->BJ = 64; }
-    else if (p.plane <= 256) { w->variant = 1; w->BJ = 64; }
-    else return COCLR_EINVAL;
-  } else if (taps == 3) {
-    if (p.plane > 256) return COCLR_EINVAL;
-    w->variant = 2; w->BJ = 128;       // NCI = 44
-  } else if (taps == 9) {
-    if (p.plane <= 256) w->variant = 3;
-    else if (p.plane <= 768) w->variant = 4;
-    else if (p.plane <= 1024) w->variant = 7;
-    else return COCLR_EINVAL;
-    w->BJ = 128;                        // NCI = 16
-  } else if (taps == 7) {
-    if (p.plane > 512) return COCLR_EINVAL;
-    w->variant = 5; w->BJ = 128;        // NCI = 20
-  } else if (taps == 49) {
-    if (p.plane > 1280) return COCLR_EINVAL;
-    w->variant = 6; w->BJ = 128;        // NCI = 4
-  } else {
-    return COCLR_EINVAL;
-  }
-  w->planeP = p.plane | 1;
+  if (p.WT > 255 || p.WH > 255 || p.WW > 255 || (1 << p.lTN) > 255) return COCLR_EINVAL;
+  w->pch = cdiv(p.plane, 64);
+  w->planeP = w->pch * 64 + 1;
+  w->BJ = taps == 1 ? 64 : 128;
+  w->nci_max = taps == 1 ? 64 : (w->BJ - 1) / taps + 2;
+  if (w->nci_max > p.Cin) w->nci_max = p.Cin;
+  // variant = PCH bucket
+  if (w->pch <= 2) w->variant = 0;
+  else if (w->pch <= 4) w->variant = 1;
+  else if (w->pch <= 8) w->variant = 2;
+  else if (w->pch <= 20) w->variant = 3;
+  else return COCLR_EINVAL;
+  const size_t lds = ((size_t)64 * 129 + 128 + (size_t)w->nci_max * w->planeP) * sizeof(float);
+  if (lds > 160 * 1024) return COCLR_EINVAL;
   w->jtiles = cdiv(J, w->BJ);
   w->mtiles = cdiv(p.Cout, 64);
-  int S = 1536 / (w->jtiles * w->mtiles);
+  // split-K: enough workgroups to fill 256 CUs x ~3, but at least 4 boxes per workgroup so
+  // the partial-sum traffic stays small next to the streamed operands
+  int S = 768 / (w->jtiles * w->mtiles);
+  if (S > p.ntiles / 4) S = p.ntiles / 4;
   if (S < 1) S = 1;
-  if (S > p.ntiles) S = p.ntiles;
   w->S = S;
   return 0;
 }
 
-template <int BJ, int NCI, int PT, int PI>
-int launch_wgrad(WgradArgs& a, hipStream_t stream) {
-  const size_t lds = ((size_t)64 * 129 + 128 + (size_t)NCI * a.planeP) * sizeof(float);
-  if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_wgrad_kernel<BJ, NCI, PT, PI>;
+template <int BJ, int PCH>
+int launch_wgrad(WgradArgs& a, const WPlan& w, hipStream_t stream) {
+  const size_t lds = ((size_t)64 * 129 + 128 + (size_t)w.nci_max * a.planeP) * sizeof(float);
+  auto kern = conv_wgrad_kernel<BJ, PCH>;
   static bool attr_done = false;
   if (!attr_done) {
     COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -309,7 +292,7 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
   if (rc) return rc;
   const ConvPlan& p = w.p;
   WgradArgs a;
-  a.x = x; a.dy = dy; a.part = workspace; a.n_index = nullptr;
+  a.x = x; a.dy = dy; a.part = workspace;
   a.x_nstride = d->x_nstride; a.dy_nstride = d->y_nstride;
   a.x_cstride = p.Ti * p.Hi * p.Wi; a.dy_cstride = p.To * p.Ho * p.Wo;
   a.N = p.N; a.Cin = p.Cin; a.Cout = p.Cout;
@@ -320,17 +303,14 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
   a.lTW = p.lTW; a.lTH = p.lTH; a.lTT = p.lTT; a.lTN = p.lTN;
   a.nbw = p.nbw; a.nbh = p.nbh; a.nbt = p.nbt; a.nbn = p.nbn;
   a.WT = p.WT; a.WH = p.WH; a.WW = p.WW; a.plane1 = p.plane1; a.plane = p.plane;
-  a.planeP = w.planeP;
+  a.planeP = w.planeP; a.pch = w.pch;
   a.ntiles = p.ntiles; a.S = w.S; a.jtiles = w.jtiles; a.mtiles = w.mtiles;
+  const bool pw = w.BJ == 64;
   switch (w.variant) {
-    case 0: rc = launch_wgrad<64, 64, 128, 1>(a, stream); break;
-    case 1: rc = launch_wgrad<64, 64, 256, 1>(a, stream); break;
-    case 2: rc = launch_wgrad<128, 44, 256, 1>(a, stream); break;
-    case 3: rc = launch_wgrad<128, 16, 256, 1>(a, stream); break;
-    case 4: rc = launch_wgrad<128, 16, 256, 3>(a, stream); break;
-    case 5: rc = launch_wgrad<128, 20, 256, 2>(a, stream); break;
-    case 6: rc = launch_wgrad<128, 4, 256, 5>(a, stream); break;
-    case 7: rc = launch_wgrad<128, 16, 256, 4>(a, stream); break;
+    case 0: rc = pw ? launch_wgrad<64, 2>(a, w, stream) : launch_wgrad<128, 2>(a, w, stream); break;
+    case 1: rc = pw ? launch_wgrad<64, 4>(a, w, stream) : launch_wgrad<128, 4>(a, w, stream); break;
+    case 2: rc = pw ? launch_wgrad<64, 8>(a, w, stream) : launch_wgrad<128, 8>(a, w, stream); break;
+    case 3: rc = pw ? launch_wgrad<64, 20>(a, w, stream) : launch_wgrad<128, 20>(a, w, stream); break;
     default: rc = COCLR_EINVAL;
   }
   if (rc) return rc;

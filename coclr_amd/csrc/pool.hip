@@ -89,6 +89,182 @@ maxpool3d_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-tiled pooling for the configurations the backbones use.  One workgroup
+// owns G whole (n, c) input volumes (<= 16384 floats together): the volume is
+// read from HBM exactly once with coalesced loads, the window scan runs out of
+// LDS with a compile-time stencil, each lane produces WPT adjacent outputs of
+// one row so every LDS row segment is read once per WPT outputs.
+// ---------------------------------------------------------------------------
+template <int KT, int KH, int KW, int ST, int SH, int SW, int WPT, bool WITH_IDX>
+__global__ void __launch_bounds__(256)
+maxpool3d_tiled_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                           int* __restrict__ idx, const PoolGeom g, int G, int planes, int tfold) {
+  extern __shared__ float tile[];   // [G][Si]
+  const int Si = g.Ti * g.Hi * g.Wi, So = g.To * g.Ho * g.Wo;
+  const int pl0 = blockIdx.x * G;
+  const int gcount = min(G, planes - pl0);
+  // ---- load: G volumes are contiguous per sample only if they share n; handle generally
+  for (int gi = 0; gi < gcount; ++gi) {
+    const int pl = pl0 + gi;
+    const int n = pl / g.C, c = pl - n * g.C;
+    const float* xp = x + (long)n * g.x_nstride + (long)c * Si;
+    float* tp = tile + gi * Si;
+    if ((Si & 3) == 0 && ((g.x_nstride & 3) == 0)) {
+      for (int i = threadIdx.x; i < (Si >> 2); i += 256)
+        reinterpret_cast<float4*>(tp)[i] = reinterpret_cast<const float4*>(xp)[i];
+    } else {
+      for (int i = threadIdx.x; i < Si; i += 256) tp[i] = xp[i];
+    }
+  }
+  __syncthreads();
+  constexpr int NR = (WPT - 1) * SW + KW;    // input columns feeding WPT outputs
+  const int OWC = (g.Wo + WPT - 1) / WPT;
+  const int rows = g.To * g.Ho;
+  const int items = gcount * rows * OWC;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int owc = it % OWC;
+    int r = it / OWC;
+    const int oh = r % g.Ho; r /= g.Ho;
+    const int ot = r % g.To;
+    const int gi = r / g.To;
+    const int ow0 = owc * WPT;
+    const float* tp = tile + gi * Si;
+    float best[WPT];
+    int bi[WPT];
+    const int t0 = ot * ST - g.pt, h0 = oh * SH - g.ph, w0 = ow0 * SW - g.pw;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      best[j] = -INFINITY;
+      // ATen initialises argmax to the first in-range window element
+      const int tt = max(t0, 0), hh = max(h0, 0), ww = max(w0 + j * SW, 0);
+      bi[j] = (tt * g.Hi + hh) * g.Wi + ww;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int t = t0 + kt;
+      if (t < 0 || t >= g.Ti) continue;
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        const int h = h0 + kh;
+        if (h < 0 || h >= g.Hi) continue;
+        const int rowoff = (t * g.Hi + h) * g.Wi;
+        float v[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          const int w = w0 + q;
+          v[q] = (w >= 0 && w < g.Wi) ? tp[rowoff + w] : -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+#pragma unroll
+          for (int kw = 0; kw < KW; ++kw) {
+            const float val = v[j * SW + kw];
+            if (val > best[j] || val != val) { best[j] = val; bi[j] = rowoff + w0 + j * SW + kw; }
+          }
+        }
+      }
+    }
+    const int pl = pl0 + gi;
+    const int n = pl / g.C, c = pl - n * g.C;
+    const long obase = ((long)ot * g.Ho + oh) * g.Wo + ow0;
+    float* yp = y + (long)n * g.y_nstride + (long)c * So + obase;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      if (ow0 + j < g.Wo) {
+        yp[j] = best[j];
+        // indices are relative to the un-folded (n, c) volume
+        if (WITH_IDX) idx[(long)pl * So + obase + j] = bi[j] + (pl % tfold) * Si;
+      }
+    }
+  }
+}
+
+// Backward: the G input-gradient volumes live in LDS; every output element scatters its
+// gradient with one LDS float atomic (order of the <= 27 addends per element is not
+// fixed: results are reproducible to fp32 round-off, not bitwise), then the tile is
+// written (or accumulated) to HBM with coalesced stores.
+__global__ void __launch_bounds__(256)
+maxpool3d_tiled_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, float* dx,
+                           const PoolGeom g, long dy_nstride, long dx_nstride, int accumulate,
+                           int G, int planes, int tfold) {
+  extern __shared__ float tile[];   // [G][Si]
+  const int Si = g.Ti * g.Hi * g.Wi, So = g.To * g.Ho * g.Wo;
+  const int pl0 = blockIdx.x * G;
+  const int gcount = min(G, planes - pl0);
+  for (int i = threadIdx.x; i < gcount * Si; i += 256) tile[i] = 0.f;
+  __syncthreads();
+  for (int gi = 0; gi < gcount; ++gi) {
+    const int pl = pl0 + gi;
+    const int n = pl / g.C, c = pl - n * g.C;
+    const float* dyp = dy + (long)n * dy_nstride + (long)c * So;
+    const int* ip = idx + (long)pl * So;
+    float* tp = tile + gi * Si;
+    const int rebase = (pl % tfold) * Si;
+    for (int o = threadIdx.x; o < So; o += 256) atomicAdd(&tp[ip[o] - rebase], dyp[o]);
+  }
+  __syncthreads();
+  for (int gi = 0; gi < gcount; ++gi) {
+    const int pl = pl0 + gi;
+    const int n = pl / g.C, c = pl - n * g.C;
+    float* dxp = dx + (long)n * dx_nstride + (long)c * Si;
+    const float* tp = tile + gi * Si;
+    if ((Si & 3) == 0 && ((dx_nstride & 3) == 0)) {
+      for (int i = threadIdx.x; i < (Si >> 2); i += 256) {
+        float4 v = reinterpret_cast<const float4*>(tp)[i];
+        if (accumulate) {
+          const float4 o = reinterpret_cast<const float4*>(dxp)[i];
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        reinterpret_cast<float4*>(dxp)[i] = v;
+      }
+    } else {
+      for (int i = threadIdx.x; i < Si; i += 256) dxp[i] = accumulate ? dxp[i] + tp[i] : tp[i];
+    }
+  }
+}
+
+constexpr int kTileFloats = 16384;   // 64 KiB of LDS per workgroup
+
+// planes per workgroup so that the tile is <= kTileFloats and there are enough workgroups
+inline int pick_group(int planes, int Si) {
+  int G = kTileFloats / Si;
+  if (G < 1) return 0;
+  while (G > 1 && (planes + G - 1) / G < 1024) G >>= 1;
+  return G;
+}
+
+template <int KT, int KH, int KW, int ST, int SH, int SW, int WPT>
+int launch_tiled_fwd(const PoolGeom& g, const float* x, float* y, int* idx, int G, int planes,
+                     int tfold, hipStream_t stream) {
+  const size_t lds = (size_t)G * g.Ti * g.Hi * g.Wi * sizeof(float);
+  const int blocks = (planes + G - 1) / G;
+  if (idx) {
+    auto k = maxpool3d_tiled_fwd_kernel<KT, KH, KW, ST, SH, SW, WPT, true>;
+    static bool done = false;
+    if (!done) { COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kTileFloats * 4)); done = true; }
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, stream, x, y, idx, g, G, planes, tfold);
+  } else {
+    auto k = maxpool3d_tiled_fwd_kernel<KT, KH, KW, ST, SH, SW, WPT, false>;
+    static bool done = false;
+    if (!done) { COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kTileFloats * 4)); done = true; }
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, stream, x, y, idx, g, G, planes, tfold);
+  }
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+// Collapse T into the plane count when the stencil does not touch it.
+inline PoolGeom fold_time(PoolGeom g) {
+  if (g.kt == 1 && g.st == 1 && g.pt == 0 && g.Ti == g.To) {
+    // (n, c, t) volumes of H*W: only valid when samples are dense in (C,T,H,W), which
+    // holds for channel-slice views as long as C*T planes of one sample are contiguous
+    g.C = g.C * g.Ti;
+    g.Ti = g.To = 1;
+  }
+  return g;
+}
+
 // y[n][c] = mean over S contiguous elements; one wave per (n, c).
 __global__ void __launch_bounds__(256)
 global_avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int S) {
@@ -134,6 +310,24 @@ extern "C" int coclr_maxpool3d_fwd(const coclr_pool_desc* d, const float* x, flo
   if (!d || d->N <= 0 || d->C <= 0) return COCLR_EINVAL;
   if (d->pt * 2 > d->kt || d->ph * 2 > d->kh || d->pw * 2 > d->kw) return COCLR_EINVAL;
   const PoolGeom g = to_geom(d);
+  {
+    // LDS-tiled fast paths; T is folded into the plane count when the stencil ignores it
+    const PoolGeom f = fold_time(g);
+    const int tfold = f.Ti == g.Ti ? 1 : g.Ti;
+    const int Si = f.Ti * f.Hi * f.Wi;
+    const int planes = f.N * f.C;
+    const int G = pick_group(planes, Si);
+    hipStream_t st = (hipStream_t)stream;
+    if (G > 0) {
+      const int k[3] = {f.kt, f.kh, f.kw}, s[3] = {f.st, f.sh, f.sw};
+#define POOL_IS(a, b, c, e, ff, gg) (k[0] == a && k[1] == b && k[2] == c && s[0] == e && s[1] == ff && s[2] == gg)
+      if (POOL_IS(1, 3, 3, 1, 2, 2)) return launch_tiled_fwd<1, 3, 3, 1, 2, 2, 2>(f, x, y, indices, G, planes, tfold, st);
+      if (POOL_IS(3, 3, 3, 1, 1, 1)) return launch_tiled_fwd<3, 3, 3, 1, 1, 1, 4>(f, x, y, indices, G, planes, tfold, st);
+      if (POOL_IS(3, 3, 3, 2, 2, 2)) return launch_tiled_fwd<3, 3, 3, 2, 2, 2, 2>(f, x, y, indices, G, planes, tfold, st);
+      if (POOL_IS(2, 2, 2, 2, 2, 2)) return launch_tiled_fwd<2, 2, 2, 2, 2, 2, 2>(f, x, y, indices, G, planes, tfold, st);
+#undef POOL_IS
+    }
+  }
   hipLaunchKernelGGL(maxpool3d_fwd_kernel, pool_grid(g.N * g.C, g.To * g.Ho * g.Wo), dim3(256), 0,
                      (hipStream_t)stream, x, y, indices, g);
   COCLR_LAUNCH_CHECK();
@@ -144,7 +338,28 @@ extern "C" int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, co
                                    float* dx, int64_t dy_nstride, int64_t dx_nstride,
                                    int accumulate, void* stream) {
   if (!d || d->N <= 0 || d->C <= 0) return COCLR_EINVAL;
-  const PoolGeom g = to_geom(d);
+  const PoolGeom g0 = to_geom(d);
+  {
+    const PoolGeom g = fold_time(g0);
+    const int tfold = g.Ti == g0.Ti ? 1 : g0.Ti;
+    const int Si = g.Ti * g.Hi * g.Wi;
+    const int planes = g.N * g.C;
+    const int G = pick_group(planes, Si);
+    if (G > 0) {
+      static bool done = false;
+      if (!done) {
+        COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool3d_tiled_bwd_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kTileFloats * 4));
+        done = true;
+      }
+      hipLaunchKernelGGL(maxpool3d_tiled_bwd_kernel, dim3((planes + G - 1) / G), dim3(256),
+                         (size_t)G * Si * sizeof(float), (hipStream_t)stream, dy, indices, dx, g,
+                         (long)dy_nstride, (long)dx_nstride, accumulate, G, planes, tfold);
+      COCLR_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  const PoolGeom& g = g0;
   hipLaunchKernelGGL(maxpool3d_bwd_kernel, pool_grid(g.N * g.C, g.Ti * g.Hi * g.Wi), dim3(256), 0,
                      (hipStream_t)stream, dy, indices, dx, g, (long)dy_nstride, (long)dx_nstride,
                      accumulate);
