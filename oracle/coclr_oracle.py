@@ -289,12 +289,20 @@ def ubernce_loss(logits, mask):
 
 
 def training_state(sd, requires_grad_prefix="encoder_q."):
-    """Detach-clone a state dict; float tensors under `requires_grad_prefix` that are
-    parameters (not BN buffers) become autograd leaves."""
-    out = {}
+    """Detach-clone a state dict (alias structure preserved); float tensors under
+    `requires_grad_prefix` that are parameters (not BN buffers) become autograd leaves."""
+    out, memo = {}, {}
     for k, v in sd.items():
+        # S3D registers every stage twice (Conv_1a.* and block1.0.*, backbone/s3dg.py:145-150):
+        # keys that alias one tensor must keep aliasing one clone
+        ident = (v.data_ptr(), tuple(v.shape), v.dtype) if v.numel() else None
+        if ident is not None and ident in memo:
+            out[k] = memo[ident]
+            continue
         v = v.detach().clone()
         if k.startswith(requires_grad_prefix) and v.is_floating_point() and not _is_buffer(k):
             v.requires_grad_(True)
         out[k] = v
+        if ident is not None:
+            memo[ident] = v
     return out

