@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -19,7 +19,8 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, i32) for n in (
         "N", "Cin", "Cout", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kt", "kh", "kw",
         "st", "sh", "sw", "pt", "ph", "pw", "dt", "dh", "dw")] + [
-        ("x_nstride", i64), ("y_nstride", i64)]
+        ("x_nstride", i64), ("y_nstride", i64)] + [(n, i32) for n in (
+        "ys_t", "ys_h", "ys_w", "yo_t", "yo_h", "yo_w", "yT", "yH", "yW", "Nx")]
 
 
 class PoolDesc(C.Structure):
@@ -33,7 +34,7 @@ _P = C.POINTER
 _SIGNATURES = {
     "coclr_abi_version": [],
     "coclr_conv_packed_size": [i32, i32, i32, i32, _P(i64)],
-    "coclr_conv_pack_weights": [vp, vp, i32, i32, i32, i64, i64, i32, i32, vp],
+    "coclr_conv_pack_weights": [vp, vp, i32, i32, i32, i64, i64, i32, i32, i32, vp],
     "coclr_conv3d_ntiles": [_P(ConvDesc), _P(i32)],
     "coclr_conv3d_fwd": [_P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "coclr_conv3d_wgrad_workspace": [_P(ConvDesc), _P(i64)],

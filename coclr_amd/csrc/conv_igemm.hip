@@ -3,32 +3,48 @@
 //   Y[n][co][o] = sum_{ci,tap} W[co][ci][tap] * V[n][ci][o*stride - pad + tap]
 //
 // where V is the input, optionally zero-upsampled ("input dilation") so the
-// same kernel serves as the data-gradient of a strided convolution.  This one
-// kernel family replaces every ATen/cuDNN conv3d the reference issues from
-// backbone/s3dg.py:11-13,39-42 and backbone/resnet_2d3d.py:53-59,138 (forward),
-// and the dgrad half of their autograd backward.
+// same kernel serves as the data-gradient of a strided convolution, and the
+// output positions may be a strided sub-lattice of the destination tensor
+// (phase-decomposed data gradient).  This one kernel family replaces every
+// ATen/cuDNN conv3d the reference issues from backbone/s3dg.py:11-13,39-42 and
+// backbone/resnet_2d3d.py:53-59,138 (forward), and the dgrad half of their
+// autograd backward.
 //
 // Mapping to the hardware:
 //   * GEMM view: M = Cout, N = output positions (a power-of-two 4-D "box"
-//     n x t x h x w owned by one workgroup), K = Cin x taps.
-//   * The input stencil window of the box is staged ONCE per Cin-chunk in LDS
-//     ([c][window], positions contiguous); every tap reads it at a shifted
-//     offset, so HBM/L2 sees each input element ~once per box instead of
-//     once per tap.
-//   * Weights arrive pre-packed as [tap][CinP][CoutP] (Cout contiguous) and are
-//     staged as [tap][c][BM]; both MFMA operand reads are stride-1 across the
-//     32 lanes of a half-wave -> conflict-free ds_read_b32.
+//     n x t x h x w owned by one workgroup), K = Cin x taps, in chunks of CC
+//     input channels.
+//   * Both operands of a chunk are brought in by the LDS-DMA engine
+//     (buffer_load_dword[x4] ... lds): no staging registers, out-of-range
+//     lanes (zero padding, box overhang, dilation holes) are dropped by the
+//     buffer bounds check and land as 0.0.  Two LDS stages: chunk i+1 streams
+//     in while chunk i is multiplied; one barrier per chunk.
+//   * The input stencil window of the box sits in LDS as [c][window]
+//     (positions contiguous); every tap reads it at a shifted offset, so
+//     HBM/L2 sees each input element ~once per box instead of once per tap.
+//   * Weights arrive pre-packed as [tap][CinP][CoutP] (Cout contiguous, padded
+//     to x128) and are staged as [tap][c][BM]; both MFMA operand reads are
+//     stride-1 across the 32 lanes of a half-wave -> conflict-free ds_read_b32.
 //   * Math: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).  Lanes 0-31 carry
 //     k = even channel of the chunk, lanes 32-63 the odd one, same tap.
-//   * 256 threads = 4 waves as 2(M) x 2(N); next chunk is prefetched into
-//     registers while the current one is multiplied.
-//   * Epilogue: optional bias / per-channel affine / ReLU / accumulate, plus
-//     per-workgroup partial sums (sum, sum of squares) per output channel for
-//     train-mode BatchNorm, written without atomics as [2][Cout][ntiles].
+//     Operands of step i+1 are fetched while the MFMAs of step i issue.
+//   * 256 threads = 4 waves as 2(M) x 2(N).
+//   * Epilogue: buffer stores with scalar row offsets (no per-element address
+//     math or exec masking), optional bias / per-channel affine / ReLU /
+//     accumulate, plus per-workgroup partial sums (sum, sum of squares) per
+//     output channel for train-mode BatchNorm, reduced with DPP row operations
+//     and written without atomics as [2][Cout][ntiles].
+#include <type_traits>
+
 #include "common.h"
 #include "conv_geom.h"
 
 namespace {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr unsigned OOB = 0x80000000u;        // byte offset no buffer below reaches
+constexpr unsigned BUF_RANGE = 0x80000000u;  // num_records of every descriptor
 
 struct ConvArgs {
   const float* x;
@@ -44,37 +60,53 @@ struct ConvArgs {
   int N, Cin, Cout, CinP, CoutP;
   int Ti, Hi, Wi, To, Ho, Wo;
   int st, sh, sw, pt, ph, pw, dt, dh, dw;
+  int yHf, yWf;                       // full H, W extent of the destination tensor
+  int yst, ysh, ysw, yot, yoh, yow;   // destination position = o * ys + yo
   int lTW, lTH, lTT, lTN;
   int nbw, nbh, nbt, nbn;
-  int WT, WH, WW, plane1, plane;
-  int mtiles, ntiles;
+  int WT, WH, WW, plane1, plane, planeS;
+  float inv_plane1, inv_hw, inv_ww;
+  int mtiles, ntiles, nchunks;
   int relu, accumulate;
 };
 
-template <int KT, int KH, int KW, int CC, int BM, int BN, int PT, int PI>
+// sum over each 16-lane row (result in every lane of the row)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x140, 0xf, 0xf, true);   // row_mirror
+  return v;
+}
+
+// exact floor(e / d) for 0 <= e < 2^20 given inv = 1.0f / d
+__device__ __forceinline__ int fdiv(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
+
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvArgs a) {
   constexpr int TAPS = KT * KH * KW;
   constexpr int WM = 2, WN = 2;
   constexpr int MF = BM / (WM * 32), NF = BN / (WN * 32);
-  constexpr int CG = 256 / PT;   // channel groups staged side by side
-  constexpr int CI = CC / CG;    // channel iterations per thread per chunk
-  static_assert(CC % CG == 0 && CC % 2 == 0, "chunk shape");
+  static_assert(CC % 4 == 0, "chunk: every wave stages CC/4 channels");
   static_assert(MF >= 1 && NF >= 1, "tile shape");
-  constexpr int W4_TOTAL = TAPS * CC * BM / 4;
-  constexpr int NW4 = (W4_TOTAL + 255) / 256;
+  constexpr int RPP = 256 / BM;                 // weight rows per 1 KiB DMA piece
+  constexpr int WPIECES = TAPS * CC / RPP;      // pieces per chunk
+  static_assert(CC % RPP == 0, "a DMA piece never straddles two taps");
+  constexpr int W_FLOATS = TAPS * CC * BM;
 
   extern __shared__ __align__(16) float smem[];
-  float* Ws = smem;                    // [TAPS*CC][BM]
-  float* Xs = smem + TAPS * CC * BM;   // [CC][plane]
+  const int planeS = a.planeS;
+  const int stage_floats = W_FLOATS + CC * planeS;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- which tile --------------------------------------------------------
-  int bid = blockIdx.x;
+  const int bid = blockIdx.x;
   const int mt = bid % a.mtiles;
   const int ntile = bid / a.mtiles;
   int r = ntile;
@@ -87,32 +119,51 @@ conv_igemm_kernel(const ConvArgs a) {
   const int vt0 = ot0 * a.st - a.pt, vh0 = oh0 * a.sh - a.ph, vw0 = ow0 * a.sw - a.pw;
   const int plane = a.plane;
 
-  // ---- per-thread staging map for the input window ------------------------
-  const int pe = tid % PT, cg = tid / PT;
-  long goff[PI];
+  // descriptors: x relative to the box's first sample (or to the tensor when samples are
+  // gathered), packed weights, y relative to the box's first sample
+  const bool gather = a.n_index != nullptr;
+  const float* xbase = gather ? a.x : a.x + (long)n0 * a.x_nstride;
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, BUF_RANGE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
+  float* ybase = a.y + (long)n0 * a.y_nstride;
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, BUF_RANGE, 0x00020000);
+
+  // ---- per-lane byte offsets of the window elements this lane's DMA pieces fetch ----
+  unsigned goff[PCH];
+  {
+    const int hw = a.WH * a.WW;
+    const bool dil = (a.dt | a.dh | a.dw) != 1;
 #pragma unroll
-  for (int i = 0; i < PI; ++i) {
-    const int e = pe + i * PT;
-    goff[i] = -1;
-    if (e < plane) {
-      const int wn_ = e / a.plane1;
-      int q = e - wn_ * a.plane1;
-      const int hw = a.WH * a.WW;
-      const int wt = q / hw; q -= wt * hw;
-      const int wh = q / a.WW;
-      const int ww = q - wh * a.WW;
-      const int n = n0 + wn_;
-      const int vt = vt0 + wt, vh = vh0 + wh, vw = vw0 + ww;
-      if (n < a.N && vt >= 0 && vh >= 0 && vw >= 0) {
-        const int it = vt / a.dt, ih = vh / a.dh, iw = vw / a.dw;
-        if (it * a.dt == vt && ih * a.dh == vh && iw * a.dw == vw &&
-            it < a.Ti && ih < a.Hi && iw < a.Wi) {
-          const long ns = a.n_index ? (long)a.n_index[n] : (long)n;
-          goff[i] = ns * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw;
+    for (int j = 0; j < PCH; ++j) {
+      const int e = j * 64 + lane;
+      unsigned off = OOB;
+      if (e < plane) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
+        const int wh = fdiv(q, a.inv_ww);
+        const int ww = q - wh * a.WW;
+        const int n = n0 + wn_;
+        int it = vt0 + wt, ih = vh0 + wh, iw = vw0 + ww;
+        bool ok = n < a.N && it >= 0 && ih >= 0 && iw >= 0;
+        if (dil && ok) {
+          const int vt = it, vh = ih, vw = iw;
+          it = vt / a.dt; ih = vh / a.dh; iw = vw / a.dw;
+          ok = it * a.dt == vt && ih * a.dh == vh && iw * a.dw == vw;
+        }
+        if (ok && it < a.Ti && ih < a.Hi && iw < a.Wi) {
+          const long ns = gather ? (long)a.n_index[n] : (long)wn_;
+          off = (unsigned)((ns * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4);
         }
       }
+      goff[j] = off;
     }
   }
+  // weights: lane's row inside a piece and column
+  const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
 
   // ---- per-lane MFMA operand bases ----------------------------------------
   int lanebase[NF];
@@ -123,8 +174,8 @@ conv_igemm_kernel(const ConvArgs a) {
     const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
     const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
     const int tn = p >> (a.lTW + a.lTH + a.lTT);
-    lanebase[nf] = tn * a.plane1 + ((tt * a.st) * a.WH + th * a.sh) * a.WW + tw * a.sw +
-                   half * plane;
+    lanebase[nf] = W_FLOATS + tn * a.plane1 + ((tt * a.st) * a.WH + th * a.sh) * a.WW +
+                   tw * a.sw + half * planeS;
   }
   const int abase = half * BM + wm * (BM / WM) + l31;
 
@@ -136,92 +187,85 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
 
-  float xr[CI][PI];
-  float4 wr[NW4];
-
-  auto load_chunk = [&](int cin0) {
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci) {
-      const int cin = cin0 + ci * CG + cg;
-      const bool cok = cin < a.Cin;
-#pragma unroll
-      for (int i = 0; i < PI; ++i) {
-        float v = 0.f;
-        if (cok && goff[i] >= 0) v = a.x[goff[i] + (long)cin * a.x_cstride];
-        xr[ci][i] = v;
-      }
+  // ---- DMA of one chunk into stage `sbase` ------------------------------------
+  auto stage = [&](int cin0, float* sbase) {
+    // weights: pieces wave, wave+4, ...
+    for (int p = wave; p < WPIECES; p += 4) {
+      const int row0 = p * RPP;
+      const int tap = row0 / CC, c0 = row0 % CC;
+      const unsigned soff = (unsigned)((((long)tap * a.CinP + cin0 + c0) * a.CoutP + cout0) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sbase + p * 256), 16, wvoff, soff, 0, 0);
     }
+    // input window: channels wave, wave+4, ...
+    float* xs = sbase + W_FLOATS;
 #pragma unroll
-    for (int i = 0; i < NW4; ++i) {
-      const int e4 = tid + i * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e4 < W4_TOTAL) {
-        const int row = e4 / (BM / 4), m4 = e4 % (BM / 4);
-        const int tap = row / CC, c = row % CC;
-        const int co = cout0 + m4 * 4;
-        if (co < a.CoutP)
-          v = *reinterpret_cast<const float4*>(
-              a.w + ((long)tap * a.CinP + cin0 + c) * a.CoutP + co);
+    for (int ci = 0; ci < CC / 4; ++ci) {
+      const int c = ci * 4 + wave;
+      const int cin = cin0 + c;
+      if (cin < a.Cin) {
+        const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
+                                                     goff[j], soff, 0, 0);
+      } else {
+        // channel past Cin: its packed weights are zero, keep the operand finite
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane) xs[c * planeS + j * 64 + lane] = 0.f;
       }
-      wr[i] = v;
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci) {
-      const int c = ci * CG + cg;
-#pragma unroll
-      for (int i = 0; i < PI; ++i) {
-        const int e = pe + i * PT;
-        if (e < plane) Xs[c * plane + e] = xr[ci][i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NW4; ++i) {
-      const int e4 = tid + i * 256;
-      if (e4 < W4_TOTAL) *reinterpret_cast<float4*>(Ws + e4 * 4) = wr[i];
     }
   };
 
-  const int nchunks = (a.Cin + CC - 1) / CC;
-  load_chunk(0);
+  // ---- main loop ---------------------------------------------------------------
+  const int nchunks = a.nchunks;
+  stage(0, smem);
   for (int ch = 0; ch < nchunks; ++ch) {
-    __syncthreads();   // previous chunk fully consumed
-    store_chunk();
-    __syncthreads();
-    if (ch + 1 < nchunks) load_chunk((ch + 1) * CC);
+    float* cur = smem + (ch & 1) * stage_floats;
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA of chunk ch has landed
+    __syncthreads();                      // ... everyone's has, and chunk ch-1 is fully consumed
+    if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((ch + 1) & 1) * stage_floats);
 
-#pragma unroll(KT > 3 && KH > 1 ? 1 : KT)
+    // Operands of MFMA step i+1 are fetched from LDS before the MFMAs of step i issue
+    // (register double buffer), so the LDS latency sits under matrix-pipe time.
+    constexpr int QS = CC / 2;
+    constexpr int STEPS_T = KH * KW * QS;      // steps per temporal tap
+    auto fetch = [&](int kt, int i, float (&av)[MF], float (&bv)[NF]) {
+      const int rr = i / QS, q = i % QS;
+      const int kh = rr / KW, kw = rr % KW;
+      const int tap = (kt * KH + kh) * KW + kw;
+      const int tapoff = (kt * a.WH + kh) * a.WW + kw;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) av[mf] = cur[abase + (tap * CC + 2 * q) * BM + mf * 32];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bv[nf] = cur[lanebase[nf] + tapoff + 2 * q * planeS];
+    };
+#pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
+      float av[2][MF], bv[2][NF];
+      fetch(kt, 0, av[0], bv[0]);
 #pragma unroll
-      for (int kh = 0; kh < KH; ++kh) {
+      for (int i = 0; i < STEPS_T; ++i) {
+        if (i + 1 < STEPS_T) fetch(kt, i + 1, av[(i + 1) & 1], bv[(i + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) {
-          const int tap = (kt * KH + kh) * KW + kw;
-          const int tapoff = (kt * a.WH + kh) * a.WW + kw;
+        for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-          for (int q = 0; q < CC / 2; ++q) {
-            float av[MF], bv[NF];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-              av[mf] = Ws[abase + (tap * CC + 2 * q) * BM + mf * 32];
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-              bv[nf] = Xs[lanebase[nf] + tapoff + 2 * q * plane];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-              for (int nf = 0; nf < NF; ++nf)
-                acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                    av[mf], bv[nf], acc[mf][nf], 0, 0, 0);
-          }
-        }
+          for (int nf = 0; nf < NF; ++nf)
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                av[i & 1][mf], bv[i & 1][nf], acc[mf][nf], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
 
   // ---- epilogue -------------------------------------------------------------
-  long yoff[NF];
+  // destination byte offset of this lane's column (relative to ybase, channel row added
+  // as a scalar), OOB when the position lies outside the tensor
+  unsigned yvoff[NF];
+  bool pvalid[NF];
+  const unsigned half_rows = (unsigned)half * 4u * (unsigned)a.y_cstride * 4u;
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
     const int p = wn * (BN / WN) + nf * 32 + l31;
@@ -230,59 +274,69 @@ conv_igemm_kernel(const ConvArgs a) {
     const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
     const int tn = p >> (a.lTW + a.lTH + a.lTT);
     const int n = n0 + tn, ot = ot0 + tt, oh = oh0 + th, ow = ow0 + tw;
-    yoff[nf] = (n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo)
-                   ? (long)n * a.y_nstride + ((long)ot * a.Ho + oh) * a.Wo + ow
-                   : -1;
+    pvalid[nf] = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
+    const long e = (long)tn * a.y_nstride +
+                   ((long)(ot * a.yst + a.yot) * a.yHf + (oh * a.ysh + a.yoh)) * a.yWf +
+                   (ow * a.ysw + a.yow);
+    yvoff[nf] = pvalid[nf] ? (unsigned)(e * 4) + half_rows : OOB;
   }
 
   const bool want_stats = a.stats != nullptr;
-  float* red = smem;  // [WN][BM][2], reused after the main loop
+  float* red = smem;  // [4 (wn, 16-lane row)][BM][2], reused after the main loop
   if (want_stats) __syncthreads();
 
+  auto emit = [&](auto acc_tag) {
+    constexpr bool ACCUM = decltype(acc_tag)::value;
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf) {
+    for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-      const int ml = wm * (BM / WM) + mf * 32 + row;
-      const int co = cout0 + ml;
-      const bool cok = co < a.Cout;
-      float s = 0.f, ss = 0.f;
-      float bia = 0.f, sc = 1.f, sf = 0.f;
-      if (cok) {
-        if (a.bias) bia = a.bias[co];
-        if (a.ep_scale) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
-      }
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);   // wave-uniform
+        const int ml = rowu + 4 * half;
+        const int co = cout0 + ml;
+        const bool cok = co < a.Cout;
+        const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+        float s = 0.f, ss = 0.f;
+        float bia = 0.f, sc = 1.f, sf = 0.f;
+        if (a.bias && cok) bia = a.bias[co];
+        if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        if (cok && yoff[nf] >= 0) {
-          float* dst = a.y + yoff[nf] + (long)co * a.y_cstride;
+        for (int nf = 0; nf < NF; ++nf) {
+          const unsigned vo = cok ? yvoff[nf] : OOB;
           float v = acc[mf][nf][i];
-          if (a.accumulate) v += *dst;
-          s += v; ss += v * v;
+          if (ACCUM) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo, soff, 0));
+          const float vm = pvalid[nf] ? v : 0.f;
+          s += vm; ss += vm * vm;
           v += bia;
           v = v * sc + sf;
           if (a.relu) v = fmaxf(v, 0.f);
-          *dst = v;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vo, soff, 0);
         }
-      }
-      if (want_stats) {
-        s = half_wave_sum(s);
-        ss = half_wave_sum(ss);
-        if (l31 == 0) {
-          red[(wn * BM + ml) * 2 + 0] = s;
-          red[(wn * BM + ml) * 2 + 1] = ss;
+        if (want_stats) {
+          s = row16_sum(s);
+          ss = row16_sum(ss);
+          if ((lane & 15) == 0) {
+            const int slot = wn * 2 + (l31 >> 4);
+            red[(slot * BM + ml) * 2 + 0] = s;
+            red[(slot * BM + ml) * 2 + 1] = ss;
+          }
         }
       }
     }
-  }
+  };
+  if (a.accumulate) emit(std::true_type{}); else emit(std::false_type{});
+
   if (want_stats) {
     __syncthreads();
     if (tid < BM) {
       const int co = cout0 + tid;
       if (co < a.Cout) {
-        const float s = red[tid * 2] + red[(BM + tid) * 2];
-        const float ss = red[tid * 2 + 1] + red[(BM + tid) * 2 + 1];
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s += red[(k * BM + tid) * 2];
+          ss += red[(k * BM + tid) * 2 + 1];
+        }
         a.stats[(long)co * a.ntiles + ntile] = s;
         a.stats[((long)a.Cout + co) * a.ntiles + ntile] = ss;
       }
@@ -292,11 +346,11 @@ conv_igemm_kernel(const ConvArgs a) {
 
 // Weight re-layout:  dst[tap][r][c]  (r < RP rows = reduction channels,
 // c < CP = produced channels), zero padded.
-//   forward : r = cin,  c = cout, src tap = tap
-//   dgrad   : r = cout, c = cin,  src tap = TAPS-1-tap (stencil flipped)
+//   forward : r = cin,  c = cout, src tap = tap_base + tap*tap_step
+//   dgrad   : r = cout, c = cin,  src tap = tap_base + (taps-1-tap)*tap_step (stencil flipped)
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst,
                                     int Cout, int Cin, int taps, long co_stride, long ci_stride,
-                                    int tap_base, int RP, int CP, int transpose) {
+                                    int tap_base, int tap_step, int RP, int CP, int transpose) {
   const long total = (long)taps * RP * CP;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
@@ -306,24 +360,30 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int tap = (int)(q / RP);
     float v = 0.f;
     if (!transpose) {
-      if (rr < Cin && c < Cout) v = w[c * co_stride + rr * ci_stride + tap_base + tap];
+      if (rr < Cin && c < Cout) v = w[c * co_stride + rr * ci_stride + tap_base + tap * tap_step];
     } else {
-      if (rr < Cout && c < Cin) v = w[rr * co_stride + c * ci_stride + tap_base + (taps - 1 - tap)];
+      if (rr < Cout && c < Cin)
+        v = w[rr * co_stride + c * ci_stride + tap_base + (taps - 1 - tap) * tap_step];
     }
     dst[e] = v;
   }
 }
 
-template <int KT, int KH, int KW, int CC, int BM, int BN, int PT, int PI>
+inline int pad_to(int v, int m) { return ((v + m - 1) / m) * m; }
+
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH>
 int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   constexpr int TAPS = KT * KH * KW;
-  if (p.plane > PT * PI) return COCLR_EINVAL;
+  if (p.plane > PCH * 64) return COCLR_EINVAL;
   a.mtiles = cdiv(a.Cout, BM);
-  const size_t lds_main = ((size_t)TAPS * CC * BM + (size_t)CC * p.plane) * sizeof(float);
-  const size_t lds_red = (size_t)2 * BM * 2 * sizeof(float);
+  a.planeS = cdiv(p.plane, 64) * 64;
+  a.nchunks = cdiv(a.Cin, CC);
+  const size_t stage = ((size_t)TAPS * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
+  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
+  const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PT, PI>;
+  auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PCH>;
   static bool attr_done = false;
   if (!attr_done) {
     COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -364,22 +424,22 @@ Choice choose_tile(const ConvPlan& base, int kt, int kh, int kw, bool has128x128
 
 extern "C" int coclr_conv_packed_size(int cin, int cout, int taps, int transpose, int64_t* elems) {
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
-  const long RP = ((r + 31) / 32) * 32, CP = ((c + 31) / 32) * 32;
+  const long RP = pad_to(r, 32), CP = pad_to(c, 128);
   *elems = (int64_t)taps * RP * CP;
   return 0;
 }
 
 extern "C" int coclr_conv_pack_weights(const float* w, float* packed, int cout, int cin, int taps,
                                        int64_t co_stride, int64_t ci_stride, int tap_base,
-                                       int transpose, void* stream) {
+                                       int tap_step, int transpose, void* stream) {
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
-  const int RP = ((r + 31) / 32) * 32, CP = ((c + 31) / 32) * 32;
+  const int RP = pad_to(r, 32), CP = pad_to(c, 128);
   const long total = (long)taps * RP * CP;
   int blocks = cdiv(total, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                     packed, cout, cin, taps, (long)co_stride, (long)ci_stride, tap_base, RP, CP,
-                     transpose);
+                     packed, cout, cin, taps, (long)co_stride, (long)ci_stride, tap_base, tap_step,
+                     RP, CP, transpose);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
@@ -412,6 +472,9 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
     c = choose_tile(*p, 3, 1, 1, true, true, 256, 256);
     conv_pick_box(p, c.lbn, 3, 1, 1);
     *variant = c.lbn == 6 ? 22 : (c.bm == 128 ? 20 : 21);
+  } else if (kt == 4 && kh == 1 && kw == 1) {
+    conv_pick_box(p, 7, 4, 1, 1);
+    *variant = 25;
   } else if (kt == 1 && kh == 7 && kw == 7) {
     conv_pick_box(p, 7, 1, 7, 7);
     *variant = 30;
@@ -448,31 +511,54 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
   a.x = x; a.w = w_packed; a.y = y; a.stats = stats; a.bias = bias;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.n_index = n_index;
   a.x_nstride = d->x_nstride; a.y_nstride = d->y_nstride;
-  a.x_cstride = p.Ti * p.Hi * p.Wi; a.y_cstride = p.To * p.Ho * p.Wo;
+  a.x_cstride = p.Ti * p.Hi * p.Wi;
   a.N = p.N; a.Cin = p.Cin; a.Cout = p.Cout;
-  a.CinP = ((p.Cin + 31) / 32) * 32; a.CoutP = ((p.Cout + 31) / 32) * 32;
+  a.CinP = pad_to(p.Cin, 32); a.CoutP = pad_to(p.Cout, 128);
   a.Ti = p.Ti; a.Hi = p.Hi; a.Wi = p.Wi; a.To = p.To; a.Ho = p.Ho; a.Wo = p.Wo;
   a.st = p.st; a.sh = p.sh; a.sw = p.sw; a.pt = p.pt; a.ph = p.ph; a.pw = p.pw;
   a.dt = p.dt; a.dh = p.dh; a.dw = p.dw;
+  // destination lattice: o*step + offset inside a (yT, yH, yW) tensor; ys_t == 0 means dense
+  const bool lattice = d->ys_t > 0;
+  if (lattice) {
+    a.yst = d->ys_t; a.ysh = d->ys_h; a.ysw = d->ys_w;
+    a.yot = d->yo_t; a.yoh = d->yo_h; a.yow = d->yo_w;
+    a.yHf = d->yH; a.yWf = d->yW;
+    a.y_cstride = d->yT * d->yH * d->yW;
+  } else {
+    a.yst = a.ysh = a.ysw = 1; a.yot = a.yoh = a.yow = 0;
+    a.yHf = p.Ho; a.yWf = p.Wo;
+    a.y_cstride = p.To * p.Ho * p.Wo;
+  }
   a.lTW = p.lTW; a.lTH = p.lTH; a.lTT = p.lTT; a.lTN = p.lTN;
   a.nbw = p.nbw; a.nbh = p.nbh; a.nbt = p.nbt; a.nbn = p.nbn;
   a.WT = p.WT; a.WH = p.WH; a.WW = p.WW; a.plane1 = p.plane1; a.plane = p.plane;
-  a.ntiles = p.ntiles; a.mtiles = 0;
+  a.inv_plane1 = 1.0f / (float)p.plane1;
+  a.inv_hw = 1.0f / (float)(p.WH * p.WW);
+  a.inv_ww = 1.0f / (float)p.WW;
+  a.ntiles = p.ntiles; a.mtiles = 0; a.planeS = 0; a.nchunks = 0;
   a.relu = relu; a.accumulate = accumulate;
+  // every byte offset a workgroup forms must stay below the descriptors' 2 GiB range
+  const double lim = 2147483648.0;
+  const double xs = n_index ? (double)(d->Nx > 0 ? d->Nx : p.N) : (double)(1 << p.lTN);
+  if ((xs * (double)a.x_nstride + (double)a.Cin * a.x_cstride) * 4.0 >= lim) return COCLR_EINVAL;
+  if (((double)(1 << p.lTN) * (double)a.y_nstride + (double)(a.Cout + 128) * a.y_cstride) * 4.0 >= lim)
+    return COCLR_EINVAL;
+  if ((double)d->kt * d->kh * d->kw * a.CinP * a.CoutP * 4.0 >= lim) return COCLR_EINVAL;
   switch (variant) {
-    case 0:  return launch_variant<1, 1, 1, 32, 128, 128, 128, 1>(a, p, stream);
-    case 1:  return launch_variant<1, 1, 1, 32, 64, 128, 128, 1>(a, p, stream);
-    case 2:  return launch_variant<1, 1, 1, 32, 64, 64, 64, 1>(a, p, stream);
-    case 3:  return launch_variant<1, 1, 1, 16, 64, 64, 256, 1>(a, p, stream);
-    case 10: return launch_variant<1, 3, 3, 8, 128, 128, 256, 1>(a, p, stream);
-    case 11: return launch_variant<1, 3, 3, 8, 64, 128, 256, 1>(a, p, stream);
-    case 12: return launch_variant<1, 3, 3, 8, 64, 64, 256, 1>(a, p, stream);
-    case 13: return launch_variant<1, 3, 3, 8, 64, 64, 256, 2>(a, p, stream);
-    case 20: return launch_variant<3, 1, 1, 8, 128, 128, 256, 1>(a, p, stream);
-    case 21: return launch_variant<3, 1, 1, 8, 64, 128, 256, 1>(a, p, stream);
-    case 22: return launch_variant<3, 1, 1, 8, 64, 64, 256, 1>(a, p, stream);
-    case 30: return launch_variant<1, 7, 7, 4, 64, 128, 256, 5>(a, p, stream);
-    case 40: return launch_variant<7, 1, 1, 8, 64, 128, 256, 2>(a, p, stream);
+    case 0:  return launch_variant<1, 1, 1, 32, 128, 128, 2>(a, p, stream);
+    case 1:  return launch_variant<1, 1, 1, 32, 64, 128, 2>(a, p, stream);
+    case 2:  return launch_variant<1, 1, 1, 32, 64, 64, 1>(a, p, stream);
+    case 3:  return launch_variant<1, 1, 1, 16, 64, 64, 4>(a, p, stream);
+    case 10: return launch_variant<1, 3, 3, 4, 128, 128, 4>(a, p, stream);
+    case 11: return launch_variant<1, 3, 3, 8, 64, 128, 4>(a, p, stream);
+    case 12: return launch_variant<1, 3, 3, 8, 64, 64, 4>(a, p, stream);
+    case 13: return launch_variant<1, 3, 3, 8, 64, 64, 8>(a, p, stream);
+    case 20: return launch_variant<3, 1, 1, 4, 128, 128, 4>(a, p, stream);
+    case 21: return launch_variant<3, 1, 1, 8, 64, 128, 4>(a, p, stream);
+    case 22: return launch_variant<3, 1, 1, 8, 64, 64, 4>(a, p, stream);
+    case 25: return launch_variant<4, 1, 1, 8, 64, 128, 4>(a, p, stream);
+    case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);
+    case 40: return launch_variant<7, 1, 1, 8, 64, 128, 8>(a, p, stream);
   }
   return COCLR_EINVAL;
 }

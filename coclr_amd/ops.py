@@ -55,7 +55,7 @@ class ConvGeom:
             raise ValueError("coclr_amd: convolution output would be empty: in %s k %s s %s p %s" %
                              (self.idim, self.k, self.s, self.p))
         self.desc = ConvDesc(self.N, self.Cin, self.Cout, *self.idim, *self.odim, *self.k,
-                             *self.s, *self.p, *self.d, 0, 0)
+                             *self.s, *self.p, *self.d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         self._cache = {}
 
     @property
@@ -121,10 +121,11 @@ def conv_packed_size(cin, cout, taps, transpose):
     return out.value
 
 
-def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose):
+def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose,
+                      tap_step=1):
     _lib.check(_lib.load().coclr_conv_pack_weights(
-        _p(w), _p(packed), cout, cin, taps, co_stride, ci_stride, tap_base, int(transpose),
-        _stream()), "conv_pack_weights")
+        _p(w), _p(packed), cout, cin, taps, co_stride, ci_stride, tap_base, tap_step,
+        int(transpose), _stream()), "conv_pack_weights")
 
 
 def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shift=None,
@@ -132,6 +133,7 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
     d = geom.desc
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(y, "y")
+    d.Nx = x.shape[0]
     _lib.check(_lib.load().coclr_conv3d_fwd(
         C.byref(d), _p(x), _p(w_packed), _p(y), _p(stats), _p(bias), _p(ep_scale), _p(ep_shift),
         _p(n_index, torch.int64), int(relu), int(accumulate), _stream()), "conv3d_fwd %s" % geom)

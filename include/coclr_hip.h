@@ -46,18 +46,28 @@ typedef struct coclr_conv_desc {
                               = forward stride when the call computes a data gradient */
   int64_t x_nstride;       /* floats between input samples  (>= Cin*Ti*Hi*Wi)  */
   int64_t y_nstride;       /* floats between output samples (>= Cout*To*Ho*Wo) */
+  /* Destination lattice (phase-decomposed data gradient of a strided conv): output
+   * position o of this launch is element o*ys + yo of a (yT, yH, yW) tensor.
+   * ys_t == 0 selects the dense case (ys = 1, yo = 0, extent = To/Ho/Wo). */
+  int32_t ys_t, ys_h, ys_w;
+  int32_t yo_t, yo_h, yo_w;
+  int32_t yT, yH, yW;
+  int32_t Nx;              /* samples addressable through n_index (0: N) */
 } coclr_conv_desc;
 
 /* Number of fp32 elements of the packed-weight buffer for one conv. */
 int coclr_conv_packed_size(int cin, int cout, int taps, int transpose, int64_t* elems);
 
-/* Re-lay [Cout][Cin][taps] weights as [taps][Cin'][Cout'] (zero padded to x32).
+/* Re-lay [Cout][Cin][taps] weights as [taps][Cin'][Cout'] (zero padded: reduction
+ * channels to x32, produced channels to x128).
  * transpose=0: operand of the forward conv; transpose=1: operand of the data
- * gradient (roles of Cin/Cout swapped, stencil flipped).  co/ci strides and
- * tap_base let a (kt,kh,kw) stencil be addressed one kt-slice at a time. */
+ * gradient (roles of Cin/Cout swapped, stencil flipped).  co/ci strides, tap_base
+ * and tap_step address a sub-stencil: source tap of packed tap t is
+ * tap_base + t*tap_step (one kt-slice of a (5,7,7) stem; the taps of one phase of a
+ * strided data gradient). */
 int coclr_conv_pack_weights(const float* w, float* packed, int cout, int cin, int taps,
-                            int64_t co_stride, int64_t ci_stride, int tap_base, int transpose,
-                            void* stream);
+                            int64_t co_stride, int64_t ci_stride, int tap_base, int tap_step,
+                            int transpose, void* stream);
 
 /* Number of per-workgroup BatchNorm partial sums coclr_conv3d_fwd will emit
  * per channel for this geometry (stats buffer = 2 * Cout * ntiles floats). */

@@ -17,16 +17,21 @@ def _r32(v):
     return (v + 31) // 32 * 32
 
 
+def _r128(v):
+    return (v + 127) // 128 * 128
+
+
 def conv_packed_size(cin, cout, taps, transpose):
     r, c = (cout, cin) if transpose else (cin, cout)
-    return taps * _r32(r) * _r32(c)
+    return taps * _r32(r) * _r128(c)
 
 
-def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose):
-    w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, taps), (co_stride, ci_stride, 1),
-                          tap_base)
+def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose,
+                      tap_step=1):
+    w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, taps),
+                          (co_stride, ci_stride, tap_step), tap_base)
     r, c = (cout, cin) if transpose else (cin, cout)
-    dst = packed.view(taps, _r32(r), _r32(c))
+    dst = packed.view(taps, _r32(r), _r128(c))
     dst.zero_()
     if transpose:
         dst[:, :cout, :cin] = w3.flip(2).permute(2, 0, 1)
@@ -36,7 +41,7 @@ def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base
 
 def _unpack(geom, wp):
     taps = geom.taps
-    w = wp.view(taps, _r32(geom.Cin), _r32(geom.Cout))[:, :geom.Cin, :geom.Cout]
+    w = wp.view(taps, _r32(geom.Cin), _r128(geom.Cout))[:, :geom.Cin, :geom.Cout]
     return w.permute(2, 1, 0).reshape(geom.Cout, geom.Cin, *geom.k).contiguous()
 
 

@@ -43,10 +43,19 @@ def test_header_is_plain_c():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.ConvDesc) == 21 * 4 + 4 + 2 * 8      # 21 int32, pad, 2 int64
-    assert _lib.ConvDesc.x_nstride.offset == 88
-    assert C.sizeof(_lib.PoolDesc) == 17 * 4 + 4 + 2 * 8
-    assert _lib.PoolDesc.x_nstride.offset == 72
+    """ctypes mirrors vs the C compiler's own layout of the header structs."""
+    src = ("#include <stdio.h>\n#include <stddef.h>\n#include \"%s\"\n"
+           "int main(void){printf(\"%%zu %%zu %%zu %%zu %%zu %%zu\\n\", sizeof(coclr_conv_desc),"
+           "offsetof(coclr_conv_desc, x_nstride), offsetof(coclr_conv_desc, ys_t),"
+           "offsetof(coclr_conv_desc, Nx), sizeof(coclr_pool_desc),"
+           "offsetof(coclr_pool_desc, x_nstride)); return 0;}\n" % HEADER)
+    open("/tmp/coclr_layout.c", "w").write(src)
+    subprocess.check_call(["gcc", "-std=c99", "/tmp/coclr_layout.c", "-o", "/tmp/coclr_layout"])
+    want = [int(v) for v in subprocess.check_output(["/tmp/coclr_layout"]).split()]
+    got = [C.sizeof(_lib.ConvDesc), _lib.ConvDesc.x_nstride.offset, _lib.ConvDesc.ys_t.offset,
+           _lib.ConvDesc.Nx.offset, C.sizeof(_lib.PoolDesc), _lib.PoolDesc.x_nstride.offset]
+    assert got == want, (got, want)
+    assert _lib.ConvDesc.x_nstride.offset == 88 and _lib.PoolDesc.x_nstride.offset == 72
 
 
 def test_planning_entry_points():
@@ -64,8 +73,8 @@ def test_planning_entry_points():
     d = g.dgrad()
     assert d.d == (2, 1, 1) and d.s == (1, 1, 1) and d.p == (3, 0, 0) and d.odim == (32, 64, 64)
     assert d.ntiles() > 0
-    assert ops.conv_packed_size(3, 64, 49, False) == 49 * 32 * 64
-    assert ops.conv_packed_size(3, 64, 49, True) == 49 * 64 * 32
+    assert ops.conv_packed_size(3, 64, 49, False) == 49 * 32 * 128
+    assert ops.conv_packed_size(3, 64, 49, True) == 49 * 64 * 128
     assert ops.gemm_workspace(32, 128, 16384, 128) == 128 * 32 * 128
 
 
