@@ -211,7 +211,7 @@ def main():
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -248,9 +248,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(rec), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        # last thing on stdout (RCCL prints its banner lazily during the run)
+        sys.stdout.flush()
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":

@@ -201,6 +201,240 @@ conv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Second-generation kernel: loader / compute wave specialisation.
+//
+//   * lanes of the B operand are input CHANNELS (row stride planeP is odd -> every
+//     ds_read_b32 is conflict free); the stencil taps are a register loop: one wave owns
+//     a 32co x 32ci x TAPS block of dW (TAPS accumulators) and reuses each dY operand for
+//     all taps.  (The first-generation kernel above maps lanes to (ci,tap) pairs and loses
+//     ~70 % of its LDS cycles to bank conflicts; it stays as the fallback for Cin = 3 and
+//     windows that do not fit two LDS stages.)
+//   * 512 threads: waves 0-3 only issue MFMAs, waves 4-7 only run the LDS-DMA engine
+//     (buffer_load_dword ... lds through bounds-checked descriptors: padding / overhang
+//     lanes land as 0.0).  Two LDS stages, ONE barrier per 64-position box: the loaders
+//     fill box b+1 while the matrix waves consume box b.
+//   * the position -> window offset of MFMA step s is wave-uniform, so it is scalar ALU
+//     work; the per-read VALU cost is a single v_add.
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr unsigned W2_OOB = 0x80000000u;
+
+struct Wgrad2Args {
+  const float* x;
+  const float* dy;
+  float* part;            // [S][Cout][J]
+  long x_nstride, dy_nstride;
+  int x_cstride, dy_cstride;
+  int N, Cin, Cout, J;
+  int Ti, Hi, Wi, To, Ho, Wo;
+  int st, sh, sw, pt, ph, pw;
+  int lTW, lTH, lTT, lTN;
+  int nbw, nbh, nbt, nbn;
+  int WT, WH, WW, plane1, plane, planeP;
+  float inv_plane1, inv_hw, inv_ww;
+  int ntiles, S;
+};
+
+__device__ __forceinline__ int w2_fdiv(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
+
+template <int KT, int KH, int KW, int MB, int NB, int PCH>
+__global__ void __launch_bounds__(512)
+conv_wgrad2_kernel(const Wgrad2Args a) {
+  constexpr int TAPS = KT * KH * KW;
+  constexpr int BP = 64;                 // positions per box
+  constexpr int BMt = 64 * MB, BCt = 64 * NB;
+  constexpr int LDY = BP + 1;
+  constexpr int STEPS = BP / 2;
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeP = a.planeP;
+  const int stage_floats = BMt * LDY + BCt * planeP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int ci0 = blockIdx.y * BCt, co0 = blockIdx.z * BMt;
+  const int nbox = (a.ntiles - split + a.S - 1) / a.S;
+  const int lW = a.lTW, lWH = a.lTW + a.lTH, lWHT = a.lTW + a.lTH + a.lTT;
+
+  if (wave >= 4) {
+    // =============================== loader waves ===============================
+    const int lw = wave - 4;
+    // box-independent decode of the elements this lane moves
+    int wn_[PCH], wt_[PCH], wh_[PCH], ww_[PCH];
+    {
+      const int hw = a.WH * a.WW;
+#pragma unroll
+      for (int j = 0; j < PCH; ++j) {
+        const int e = j * 64 + lane;
+        const int q0 = w2_fdiv(e, a.inv_plane1);
+        int q = e - q0 * a.plane1;
+        const int t = w2_fdiv(q, a.inv_hw); q -= t * hw;
+        const int h = w2_fdiv(q, a.inv_ww);
+        wn_[j] = q0; wt_[j] = t; wh_[j] = h; ww_[j] = q - h * a.WW;
+      }
+    }
+    const int ptw = lane & ((1 << lW) - 1);
+    const int pth = (lane >> lW) & ((1 << a.lTH) - 1);
+    const int ptt = (lane >> lWH) & ((1 << a.lTT) - 1);
+    const int ptn = lane >> lWHT;
+
+    for (int b = 0; b < nbox; ++b) {
+      const int tile = split + b * a.S;
+      int r = tile;
+      const int bw_ = r % a.nbw; r /= a.nbw;
+      const int bh_ = r % a.nbh; r /= a.nbh;
+      const int bt_ = r % a.nbt; r /= a.nbt;
+      const int n0 = r << a.lTN;
+      const int ow0 = bw_ << lW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;
+      float* dYs = smem + (b & 1) * stage_floats;
+      float* Xs = dYs + BMt * LDY;
+
+      // ---- dY[BMt][64]: rows lw, lw+4, ... ----------------------------------------
+      {
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.dy + (long)n0 * a.dy_nstride), 0, 0x80000000u, 0x00020000);
+        const int n = n0 + ptn, ot = ot0 + ptt, oh = oh0 + pth, ow = ow0 + ptw;
+        const bool ok = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
+        const unsigned voff =
+            ok ? (unsigned)(((long)ptn * a.dy_nstride + ((long)ot * a.Ho + oh) * a.Wo + ow) * 4)
+               : W2_OOB;
+        for (int row = lw; row < BMt; row += 4) {
+          const int co = co0 + row;
+          if (co < a.Cout)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(dYs + row * LDY), 4, voff,
+                                                     (unsigned)co * (unsigned)a.dy_cstride * 4u,
+                                                     0, 0);
+          else if (b < 2)
+            dYs[row * LDY + lane] = 0.f;
+        }
+      }
+      // ---- X window: channels lw, lw+4, ... ----------------------------------------
+      {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.x + (long)n0 * a.x_nstride), 0, 0x80000000u, 0x00020000);
+        const int vt0 = ot0 * a.st - a.pt, vh0 = oh0 * a.sh - a.ph, vw0 = ow0 * a.sw - a.pw;
+        unsigned voff[PCH];
+#pragma unroll
+        for (int j = 0; j < PCH; ++j) {
+          const int n = n0 + wn_[j], it = vt0 + wt_[j], ih = vh0 + wh_[j], iw = vw0 + ww_[j];
+          const bool ok = n < a.N && it >= 0 && ih >= 0 && iw >= 0 && it < a.Ti && ih < a.Hi &&
+                          iw < a.Wi;
+          voff[j] = ok ? (unsigned)(((long)wn_[j] * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi +
+                                     iw) * 4)
+                       : W2_OOB;
+        }
+        for (int c = lw; c < BCt; c += 4) {
+          const int ci = ci0 + c;
+          if (ci < a.Cin) {
+            const unsigned soff = (unsigned)ci * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+            for (int j = 0; j < PCH; ++j)
+              if (j * 64 + lane < a.plane)     // exec-masked: rows are packed at planeP
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(Xs + c * planeP + j * 64), 4,
+                                                         voff[j], soff, 0, 0);
+          } else if (b < 2) {
+#pragma unroll
+            for (int j = 0; j < PCH; ++j)
+              if (j * 64 + lane < a.plane) Xs[c * planeP + j * 64 + lane] = 0.f;
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of box b is in LDS
+      __syncthreads();                      // barrier b
+    }
+    return;
+  }
+
+  // ================================ matrix waves ================================
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  int abase[MB], jb[NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) abase[mb] = ((wm * MB + mb) * 32 + l31) * LDY + half;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    jb[nb] = BMt * LDY + ((wn * NB + nb) * 32 + l31) * planeP + half * a.sw;
+
+  f32x16 acc[MB][NB][TAPS];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][nb][t][i] = 0.f;
+
+  // window offset of position 2s (wave-uniform: scalar ALU)
+  auto wo_of = [&](int s) {
+    const int p0 = 2 * s;
+    const int tw = p0 & ((1 << lW) - 1);
+    const int th = (p0 >> lW) & ((1 << a.lTH) - 1);
+    const int tt = (p0 >> lWH) & ((1 << a.lTT) - 1);
+    const int tn = p0 >> lWHT;
+    return tn * a.plane1 + ((tt * a.st) * a.WH + th * a.sh) * a.WW + tw * a.sw;
+  };
+
+  for (int b = 0; b < nbox; ++b) {
+    const float* cur = smem + (b & 1) * stage_floats;
+    __syncthreads();   // barrier b: box b is in LDS, box b-1 fully consumed
+
+    float av[2][MB], bv[2][NB][TAPS];
+    auto fetch = [&](int s, float (&A)[MB], float (&B)[NB][TAPS]) {
+      const int wo = wo_of(s);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) A[mb] = cur[abase[mb] + 2 * s];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int xb = jb[nb] + wo;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int kt = t / (KH * KW), kh = (t / KW) % KH, kw = t % KW;
+          B[nb][t] = cur[xb + (kt * a.WH + kh) * a.WW + kw];
+        }
+      }
+    };
+    fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      if (s + 1 < STEPS) fetch(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                av[s & 1][mb], bv[s & 1][nb][t], acc[mb][nb][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // partial tile out: part[split][co][ci*TAPS + t]
+  float* out = a.part + (long)split * a.Cout * a.J;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co0 + (wm * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int ci = ci0 + (wn * NB + nb) * 32 + l31;
+          if (ci < a.Cin) {
+            float* dst = out + (long)co * a.J + ci * TAPS;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) dst[t] = acc[mb][nb][t][i];
+          }
+        }
+      }
+    }
+}
+
 // dW[co][ci*ci_stride' ...] = sum_s part[s][e]; destination may be a tap slice of a
 // larger stencil (r50 stem): e = co*J + ci*taps + tap ->
 // dst[co*co_stride + ci*ci_stride + tap_base + tap].
@@ -222,11 +456,58 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 struct WPlan {
   ConvPlan p;
   int variant, BJ, S, jtiles, mtiles, planeP, pch, nci_max;
+  // second-generation kernel
+  int v2;            // 0: not applicable, else variant id
+  ConvPlan p2;
+  int S2, planeP2, mt2, ct2;
+  size_t lds2;
 };
+
+// tile of the v2 kernel for a stencil: returns variant id or 0
+int pick_v2(const coclr_conv_desc* d, WPlan* w) {
+  const int kt = d->kt, kh = d->kh, kw = d->kw;
+  int MB = 1, NB = 1, id = 0;
+  if (kt == 1 && kh == 3 && kw == 3) id = 1;
+  else if (kt == 3 && kh == 1 && kw == 1) id = 2;
+  else if (kt == 7 && kh == 1 && kw == 1) id = 3;
+  else if (kt == 1 && kh == 1 && kw == 1) {
+    if (d->st != 1 || d->sh != 1 || d->sw != 1) return 0;
+    if (d->Cin > 64 && d->Cout > 64) { id = 4; MB = NB = 2; } else id = 5;
+  } else return 0;
+  // narrow layers: a 64co x 64ci workgroup tile would be mostly padding; the (ci,tap)-lane
+  // kernel packs them better
+  if (id <= 3 && (d->Cin < 48 || d->Cout < 48)) return 0;
+  if (d->Cin < 8) return 0;
+  ConvPlan& p = w->p2;
+  conv_normalise(d, &p);
+  conv_pick_box(&p, 6, kt, kh, kw);
+  if (p.lTW < 1) return 0;
+  const int pch = cdiv(p.plane, 64);
+  const int maxpch = id == 1 ? 3 : (id == 3 ? 4 : 2);
+  if (pch > maxpch) return 0;
+  w->planeP2 = p.plane | 1;
+  const size_t stage = ((size_t)64 * MB * 65 + (size_t)64 * NB * w->planeP2) * sizeof(float);
+  w->lds2 = 2 * stage;
+  if (w->lds2 > 160 * 1024) return 0;
+  // every byte offset formed inside a box stays below the 2 GiB descriptor range
+  const double lim = 2147483648.0;
+  if (((double)(1 << p.lTN) * d->x_nstride + (double)p.Cin * p.Ti * p.Hi * p.Wi) * 4.0 >= lim) return 0;
+  if (((double)(1 << p.lTN) * d->y_nstride + (double)p.Cout * p.To * p.Ho * p.Wo) * 4.0 >= lim) return 0;
+  w->mt2 = cdiv(p.Cout, 64 * MB);
+  w->ct2 = cdiv(p.Cin, 64 * NB);
+  // one 512-thread workgroup per CU; two rounds of workgroups, >= 4 boxes each
+  int S = 512 / (w->mt2 * w->ct2);
+  if (S > p.ntiles / 4) S = p.ntiles / 4;
+  if (S < 1) S = 1;
+  w->S2 = S;
+  return id;
+}
 
 int plan_wgrad(const coclr_conv_desc* d, WPlan* w) {
   if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return COCLR_EINVAL;
   if (d->dt != 1 || d->dh != 1 || d->dw != 1) return COCLR_EINVAL;
+  w->v2 = pick_v2(d, w);
+  if (w->v2) return 0;
   ConvPlan& p = w->p;
   conv_normalise(d, &p);
   const int taps = d->kt * d->kh * d->kw;
@@ -272,13 +553,27 @@ int launch_wgrad(WgradArgs& a, const WPlan& w, hipStream_t stream) {
   return 0;
 }
 
+template <int KT, int KH, int KW, int MB, int NB, int PCH>
+int launch_wgrad2(const Wgrad2Args& a, const WPlan& w, hipStream_t stream) {
+  auto kern = conv_wgrad2_kernel<KT, KH, KW, MB, NB, PCH>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(512), w.lds2, stream, a);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* elems) {
   WPlan w;
   int rc = plan_wgrad(d, &w);
   if (rc) return rc;
-  *elems = (int64_t)w.S * d->Cout * d->Cin * d->kt * d->kh * d->kw;
+  *elems = (int64_t)(w.v2 ? w.S2 : w.S) * d->Cout * d->Cin * d->kt * d->kh * d->kw;
   return 0;
 }
 
@@ -290,35 +585,70 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
   WPlan w;
   int rc = plan_wgrad(d, &w);
   if (rc) return rc;
-  const ConvPlan& p = w.p;
-  WgradArgs a;
-  a.x = x; a.dy = dy; a.part = workspace;
-  a.x_nstride = d->x_nstride; a.dy_nstride = d->y_nstride;
-  a.x_cstride = p.Ti * p.Hi * p.Wi; a.dy_cstride = p.To * p.Ho * p.Wo;
-  a.N = p.N; a.Cin = p.Cin; a.Cout = p.Cout;
-  a.taps = d->kt * d->kh * d->kw; a.KH = d->kh; a.KW = d->kw;
-  a.J = p.Cin * a.taps;
-  a.Ti = p.Ti; a.Hi = p.Hi; a.Wi = p.Wi; a.To = p.To; a.Ho = p.Ho; a.Wo = p.Wo;
-  a.st = p.st; a.sh = p.sh; a.sw = p.sw; a.pt = p.pt; a.ph = p.ph; a.pw = p.pw;
-  a.lTW = p.lTW; a.lTH = p.lTH; a.lTT = p.lTT; a.lTN = p.lTN;
-  a.nbw = p.nbw; a.nbh = p.nbh; a.nbt = p.nbt; a.nbn = p.nbn;
-  a.WT = p.WT; a.WH = p.WH; a.WW = p.WW; a.plane1 = p.plane1; a.plane = p.plane;
-  a.planeP = w.planeP; a.pch = w.pch;
-  a.ntiles = p.ntiles; a.S = w.S; a.jtiles = w.jtiles; a.mtiles = w.mtiles;
-  const bool pw = w.BJ == 64;
-  switch (w.variant) {
-    case 0: rc = pw ? launch_wgrad<64, 2>(a, w, stream) : launch_wgrad<128, 2>(a, w, stream); break;
-    case 1: rc = pw ? launch_wgrad<64, 4>(a, w, stream) : launch_wgrad<128, 4>(a, w, stream); break;
-    case 2: rc = pw ? launch_wgrad<64, 8>(a, w, stream) : launch_wgrad<128, 8>(a, w, stream); break;
-    case 3: rc = pw ? launch_wgrad<64, 20>(a, w, stream) : launch_wgrad<128, 20>(a, w, stream); break;
-    default: rc = COCLR_EINVAL;
+  const int taps = d->kt * d->kh * d->kw;
+  int S_used;
+  if (w.v2) {
+    const ConvPlan& p = w.p2;
+    Wgrad2Args a;
+    a.x = x; a.dy = dy; a.part = workspace;
+    a.x_nstride = d->x_nstride; a.dy_nstride = d->y_nstride;
+    a.x_cstride = p.Ti * p.Hi * p.Wi; a.dy_cstride = p.To * p.Ho * p.Wo;
+    a.N = p.N; a.Cin = p.Cin; a.Cout = p.Cout; a.J = p.Cin * taps;
+    a.Ti = p.Ti; a.Hi = p.Hi; a.Wi = p.Wi; a.To = p.To; a.Ho = p.Ho; a.Wo = p.Wo;
+    a.st = p.st; a.sh = p.sh; a.sw = p.sw; a.pt = p.pt; a.ph = p.ph; a.pw = p.pw;
+    a.lTW = p.lTW; a.lTH = p.lTH; a.lTT = p.lTT; a.lTN = p.lTN;
+    a.nbw = p.nbw; a.nbh = p.nbh; a.nbt = p.nbt; a.nbn = p.nbn;
+    a.WT = p.WT; a.WH = p.WH; a.WW = p.WW; a.plane1 = p.plane1; a.plane = p.plane;
+    a.planeP = w.planeP2;
+    a.inv_plane1 = 1.0f / (float)p.plane1;
+    a.inv_hw = 1.0f / (float)(p.WH * p.WW);
+    a.inv_ww = 1.0f / (float)p.WW;
+    a.ntiles = p.ntiles; a.S = w.S2;
+    const int pch = cdiv(p.plane, 64);
+    switch (w.v2) {
+      case 1: rc = pch <= 2 ? launch_wgrad2<1, 3, 3, 1, 1, 2>(a, w, stream)
+                            : launch_wgrad2<1, 3, 3, 1, 1, 3>(a, w, stream); break;
+      case 2: rc = launch_wgrad2<3, 1, 1, 1, 1, 2>(a, w, stream); break;
+      case 3: rc = launch_wgrad2<7, 1, 1, 1, 1, 4>(a, w, stream); break;
+      case 4: rc = launch_wgrad2<1, 1, 1, 2, 2, 2>(a, w, stream); break;
+      case 5: rc = launch_wgrad2<1, 1, 1, 1, 1, 2>(a, w, stream); break;
+      default: rc = COCLR_EINVAL;
+    }
+    if (rc) return rc;
+    S_used = w.S2;
+  } else {
+    const ConvPlan& p = w.p;
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.part = workspace;
+    a.x_nstride = d->x_nstride; a.dy_nstride = d->y_nstride;
+    a.x_cstride = p.Ti * p.Hi * p.Wi; a.dy_cstride = p.To * p.Ho * p.Wo;
+    a.N = p.N; a.Cin = p.Cin; a.Cout = p.Cout;
+    a.taps = taps; a.KH = d->kh; a.KW = d->kw;
+    a.J = p.Cin * a.taps;
+    a.Ti = p.Ti; a.Hi = p.Hi; a.Wi = p.Wi; a.To = p.To; a.Ho = p.Ho; a.Wo = p.Wo;
+    a.st = p.st; a.sh = p.sh; a.sw = p.sw; a.pt = p.pt; a.ph = p.ph; a.pw = p.pw;
+    a.lTW = p.lTW; a.lTH = p.lTH; a.lTT = p.lTT; a.lTN = p.lTN;
+    a.nbw = p.nbw; a.nbh = p.nbh; a.nbt = p.nbt; a.nbn = p.nbn;
+    a.WT = p.WT; a.WH = p.WH; a.WW = p.WW; a.plane1 = p.plane1; a.plane = p.plane;
+    a.planeP = w.planeP; a.pch = w.pch;
+    a.ntiles = p.ntiles; a.S = w.S; a.jtiles = w.jtiles; a.mtiles = w.mtiles;
+    const bool pw = w.BJ == 64;
+    switch (w.variant) {
+      case 0: rc = pw ? launch_wgrad<64, 2>(a, w, stream) : launch_wgrad<128, 2>(a, w, stream); break;
+      case 1: rc = pw ? launch_wgrad<64, 4>(a, w, stream) : launch_wgrad<128, 4>(a, w, stream); break;
+      case 2: rc = pw ? launch_wgrad<64, 8>(a, w, stream) : launch_wgrad<128, 8>(a, w, stream); break;
+      case 3: rc = pw ? launch_wgrad<64, 20>(a, w, stream) : launch_wgrad<128, 20>(a, w, stream); break;
+      default: rc = COCLR_EINVAL;
+    }
+    if (rc) return rc;
+    S_used = w.S;
   }
-  if (rc) return rc;
-  const long CJ = (long)a.Cout * a.J;
+  const int J = d->Cin * taps;
+  const long CJ = (long)d->Cout * J;
   int blocks = cdiv(CJ, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, CJ,
-                     a.S, a.J, a.taps, (long)w_co_stride, (long)w_ci_stride, tap_base, accumulate);
+                     S_used, J, taps, (long)w_co_stride, (long)w_ci_stride, tap_base, accumulate);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
