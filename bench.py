@@ -252,6 +252,8 @@ def main():
     dist.destroy_process_group()
     if rank == 0:
         # last thing on stdout (RCCL prints its banner lazily during the run)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL's banner sits in the C stdio buffer
         sys.stdout.flush()
         print(json.dumps(rec), flush=True)
 

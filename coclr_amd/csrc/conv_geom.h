@@ -34,9 +34,14 @@ static inline void conv_normalise(const coclr_conv_desc* d, ConvPlan* p) {
   p->st = d->st; p->sh = d->sh; p->sw = d->sw;
   p->pt = d->pt; p->ph = d->ph; p->pw = d->pw;
   p->dt = d->dt; p->dh = d->dh; p->dw = d->dw;
-  const bool h_free = d->kh == 1 && d->sh == 1 && d->ph == 0 && d->dh == 1 && d->Hi == d->Ho;
-  const bool w_free = d->kw == 1 && d->sw == 1 && d->pw == 0 && d->dw == 1 && d->Wi == d->Wo;
-  const bool t_free = d->kt == 1 && d->st == 1 && d->pt == 0 && d->dt == 1 && d->Ti == d->To;
+  // a destination lattice (ys_t > 0) pins the axes it steps along
+  const bool lat = d->ys_t > 0;
+  const bool h_free = d->kh == 1 && d->sh == 1 && d->ph == 0 && d->dh == 1 && d->Hi == d->Ho &&
+                      (!lat || (d->ys_h == 1 && d->yo_h == 0 && d->yH == d->Ho));
+  const bool w_free = d->kw == 1 && d->sw == 1 && d->pw == 0 && d->dw == 1 && d->Wi == d->Wo &&
+                      (!lat || (d->ys_w == 1 && d->yo_w == 0 && d->yW == d->Wo));
+  const bool t_free = d->kt == 1 && d->st == 1 && d->pt == 0 && d->dt == 1 && d->Ti == d->To &&
+                      (!lat || (d->ys_t == 1 && d->yo_t == 0 && d->yT == d->To));
   if (h_free && w_free) {
     p->Wi = p->Wo = d->Hi * d->Wi;
     p->Hi = p->Ho = 1;

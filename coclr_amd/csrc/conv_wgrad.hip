@@ -438,18 +438,37 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
 // dW[co][ci*ci_stride' ...] = sum_s part[s][e]; destination may be a tap slice of a
 // larger stencil (r50 stem): e = co*J + ci*taps + tap ->
 // dst[co*co_stride + ci*ci_stride + tap_base + tap].
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long CJ,
-                                    int S, int J, int taps, long co_stride, long ci_stride,
-                                    int tap_base, int accumulate) {
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < CJ;
-       e += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[(long)k * CJ + e];
-    const long co = e / J;
-    const int j = (int)(e - co * J);
-    const int ci = j / taps, tap = j - ci * taps;
-    float* d = dw + co * co_stride + ci * ci_stride + tap_base + tap;
-    *d = accumulate ? *d + s : s;
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long CJ, int S, int J,
+                    int taps, long co_stride, long ci_stride, int tap_base, int accumulate) {
+  // 64 consecutive elements x 4 split groups per block; 4 independent loads in flight per
+  // thread, fixed summation order (deterministic)
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (long e0 = (long)blockIdx.x * 64; e0 < CJ; e0 += (long)gridDim.x * 64) {
+    const long e = e0 + tx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < CJ) {
+      int k = ty;
+      for (; k + 12 < S; k += 16) {
+        s0 += part[(long)k * CJ + e];
+        s1 += part[(long)(k + 4) * CJ + e];
+        s2 += part[(long)(k + 8) * CJ + e];
+        s3 += part[(long)(k + 12) * CJ + e];
+      }
+      for (; k < S; k += 4) s0 += part[(long)k * CJ + e];
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && e < CJ) {
+      const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+      const long co = e / J;
+      const int j = (int)(e - co * J);
+      const int ci = j / taps, tap = j - ci * taps;
+      float* d = dw + co * co_stride + ci * ci_stride + tap_base + tap;
+      *d = accumulate ? *d + s : s;
+    }
+    __syncthreads();
   }
 }
 
@@ -645,8 +664,8 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
   }
   const int J = d->Cin * taps;
   const long CJ = (long)d->Cout * J;
-  int blocks = cdiv(CJ, 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = cdiv(CJ, 64);
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, CJ,
                      S_used, J, taps, (long)w_co_stride, (long)w_ci_stride, tap_base, accumulate);
   COCLR_LAUNCH_CHECK();

@@ -97,17 +97,20 @@ class Run:
         return self.grads
 
     # -- weight packing ------------------------------------------------------------
-    def pack(self, w, transpose, kt_slice=None):
-        """[Cout][Cin][taps] -> [taps][Cin'][Cout'] (or the dgrad operand)."""
+    def pack(self, w, transpose, kt_slice=None, taps=None, tap_base=0, tap_step=1):
+        """[Cout][Cin][taps] -> [taps][Cin'][Cout'] (or the dgrad operand).  kt_slice picks
+        one temporal slice of the stencil; (taps, tap_base, tap_step) an arithmetic subset."""
         cout, cin, kt, kh, kw = w.shape
-        if kt_slice is None:
+        if taps is not None:
+            base = tap_base
+        elif kt_slice is None:
             taps, base = kt * kh * kw, 0
         else:
             taps, base = kh * kw, kt_slice * kh * kw
         n = ops.conv_packed_size(cin, cout, taps, transpose)
         packed = self.empty(n)
         ops.conv_pack_weights(w, packed, cout, cin, taps, cin * kt * kh * kw, kt * kh * kw, base,
-                              transpose)
+                              transpose, tap_step)
         return packed
 
 
@@ -228,7 +231,14 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                 if sliced:
                     raise NotImplementedError("coclr_amd: dgrad of the sliced stem conv")
                 dx, acc = run.grad_target(x)
-                ops.conv_fwd(geoms[0].dgrad(), dy, run.pack(w, True), dx, accumulate=acc)
+                phases = geoms[0].dgrad_phases()
+                if phases is not None:
+                    # strided conv: one dense stride-1 correlation per residue class of dX
+                    for pg, k0, nk, step in phases:
+                        ops.conv_fwd(pg, dy, run.pack(w, True, taps=nk, tap_base=k0,
+                                                      tap_step=step), dx, accumulate=acc)
+                else:
+                    ops.conv_fwd(geoms[0].dgrad(), dy, run.pack(w, True), dx, accumulate=acc)
 
         run.tape.append(backward)
     elif y is not None:

@@ -74,6 +74,17 @@ class GlobalAvgPool3d(nn.AdaptiveAvgPool3d):
         return _AvgPoolFn.apply(x)
 
 
+def _gemm_auto(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K):
+    """ops.gemm with split-K sized so a skinny product (M = batch) still fills the chip:
+    a 32 x 1024 x 1024 head layer is 8 output tiles -- split K until ~256 workgroups."""
+    tiles = ((N + 127) // 128) * ((M + 31) // 32)
+    splits = max(1, min(K // 32, 256 // tiles))
+    ws = None
+    if splits > 1:
+        ws = torch.empty(ops.gemm_workspace(M, N, K, splits), dtype=c.dtype, device=c.device)
+    ops.gemm(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, splits=splits, workspace=ws)
+
+
 class _PointwiseFn(torch.autograd.Function):
     """y[n][co] = sum_ci x[n][ci] w[co][ci] + b[co] on pooled (N,C,1,1,1) features."""
 
@@ -84,7 +95,7 @@ class _PointwiseFn(torch.autograd.Function):
         x2 = x.reshape(N, Cin).contiguous()
         w2 = w.reshape(Cout, Cin)
         y = torch.empty(N, Cout, dtype=x.dtype, device=x.device)
-        ops.gemm(x2, Cin, 1, w2, 1, Cin, y, Cout, b, N, Cout, Cin)
+        _gemm_auto(x2, Cin, 1, w2, 1, Cin, y, Cout, b, N, Cout, Cin)
         ctx.save_for_backward(x2, w2)
         ctx.has_bias = b is not None
         return y.view(N, Cout, 1, 1, 1)
@@ -98,12 +109,12 @@ class _PointwiseFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
-            ops.gemm(dy2, Cout, 1, w2, Cin, 1, dx, Cin, None, N, Cin, Cout)
+            _gemm_auto(dy2, Cout, 1, w2, Cin, 1, dx, Cin, None, N, Cin, Cout)
             dx = dx.view(N, Cin, 1, 1, 1)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w2)
             # dw[co][ci] = sum_n dy[n][co] x[n][ci]
-            ops.gemm(dy2, 1, Cout, x2, Cin, 1, dw, Cin, None, Cout, Cin, N)
+            _gemm_auto(dy2, 1, Cout, x2, Cin, 1, dw, Cin, None, Cout, Cin, N)
             dw = dw.view(Cout, Cin, 1, 1, 1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Cout, dtype=dy.dtype, device=dy.device)

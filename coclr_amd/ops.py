@@ -41,9 +41,10 @@ def _chk5(t, name):
 class ConvGeom:
     """Geometry of one 3D convolution (python mirror of coclr_conv_desc)."""
 
-    __slots__ = ("N", "Cin", "Cout", "idim", "odim", "k", "s", "p", "d", "desc", "_cache")
+    __slots__ = ("N", "Cin", "Cout", "idim", "odim", "k", "s", "p", "d", "lattice", "desc",
+                 "_cache")
 
-    def __init__(self, N, Cin, Cout, idim, k, s, p, d=(1, 1, 1), odim=None):
+    def __init__(self, N, Cin, Cout, idim, k, s, p, d=(1, 1, 1), odim=None, lattice=None):
         self.N, self.Cin, self.Cout = int(N), int(Cin), int(Cout)
         self.idim = tuple(int(v) for v in idim)
         self.k, self.s, self.p, self.d = (tuple(int(v) for v in t) for t in (k, s, p, d))
@@ -54,8 +55,13 @@ class ConvGeom:
         if min(self.odim) <= 0:
             raise ValueError("coclr_amd: convolution output would be empty: in %s k %s s %s p %s" %
                              (self.idim, self.k, self.s, self.p))
+        # lattice = (step, offset, full dims): output position o lands on element
+        # o*step + offset of a tensor of extent `full dims` (one phase of a strided dgrad)
+        self.lattice = lattice
+        lat = (0,) * 9 if lattice is None else tuple(lattice[0]) + tuple(lattice[1]) + \
+            tuple(lattice[2])
         self.desc = ConvDesc(self.N, self.Cin, self.Cout, *self.idim, *self.odim, *self.k,
-                             *self.s, *self.p, *self.d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+                             *self.s, *self.p, *self.d, 0, 0, *lat, 0)
         self._cache = {}
 
     @property
@@ -74,6 +80,39 @@ class ConvGeom:
                          d=self.s, odim=self.idim)
             self._cache["dgrad"] = g
         return g
+
+    def dgrad_phases(self):
+        """Data gradient of a conv strided along ONE axis whose stencil is 1 on the other
+        two (S3D's temporal stem conv, backbone/s3dg.py:41), as `stride` dense stride-1
+        correlations over dY, each writing one residue class of dX -- no multiply-by-zero
+        work, unlike `dgrad()`.  Returns [(geom, tap_base, ntaps, tap_step)] or None when
+        the geometry is not of that form."""
+        g = self._cache.get("phases", False)
+        if g is not False:
+            return g
+        out = None
+        axes = [i for i in range(3) if self.s[i] > 1]
+        if len(axes) == 1 and self.d == (1, 1, 1):
+            ax = axes[0]
+            others = [i for i in range(3) if i != ax]
+            if all(self.k[i] == 1 and self.p[i] == 0 for i in others) and ax == 0:
+                st, K, P = self.s[ax], self.k[ax], self.p[ax]
+                out = []
+                for phi in range(st):
+                    k0 = (phi + P) % st
+                    nk = (K - k0 + st - 1) // st
+                    m_phi = (self.idim[ax] - phi + st - 1) // st
+                    if nk not in (1, 3, 4) or m_phi <= 0:
+                        out = None
+                        break
+                    c = (phi + P - k0) // st
+                    kk, pp, od, ys, yo = [1, 1, 1], [0, 0, 0], list(self.idim), [1, 1, 1], [0, 0, 0]
+                    kk[ax], pp[ax], od[ax], ys[ax], yo[ax] = nk, nk - 1 - c, m_phi, st, phi
+                    geom = ConvGeom(self.N, self.Cout, self.Cin, self.odim, kk, (1, 1, 1), pp,
+                                    odim=od, lattice=(ys, yo, self.idim))
+                    out.append((geom, k0, nk, st))
+        self._cache["phases"] = out
+        return out
 
     def ntiles(self):
         v = self._cache.get("ntiles")

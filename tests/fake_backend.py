@@ -80,6 +80,9 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
              n_index=None, relu=False, accumulate=False):
     w = _unpack(geom, w_packed)
     raw = _conv_raw(geom, _virtual_input(geom, x, n_index), w)
+    if getattr(geom, "lattice", None) is not None:
+        ys, yo, _ = geom.lattice
+        y = y[:, :, yo[0]::ys[0], yo[1]::ys[1], yo[2]::ys[2]]     # view: copy_ below lands in place
     if accumulate:
         raw = raw + y
     if stats is not None:

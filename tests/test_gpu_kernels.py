@@ -105,6 +105,37 @@ def test_conv_dgrad_wgrad(case):
     close(dw, w.grad, what="wgrad")
 
 
+@pytest.mark.parametrize("T", [8, 9, 32])
+def test_conv_dgrad_phase_decomposition(T):
+    """Strided temporal stem conv (backbone/s3dg.py:41): its data gradient as two dense
+    stride-1 correlations writing the even / odd frames of dX, plain and accumulated."""
+    from coclr_amd import ops, engine
+    N, Cin, Cout, dims, k, s, p = 2, 64, 64, (T, 12, 12), (7, 1, 1), (2, 1, 1), (3, 0, 0)
+    torch.manual_seed(5)
+    x = torch.randn(N, Cin, *dims, requires_grad=True)
+    w = (torch.randn(Cout, Cin, *k) * 0.05).requires_grad_(True)
+    ref = F.conv3d(x, w, None, s, p)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    g = ops.ConvGeom(N, Cin, Cout, dims, k, s, p)
+    phases = g.dgrad_phases()
+    assert phases is not None and len(phases) == 2
+    assert sorted(nk for _, _, nk, _ in phases) == [3, 4]
+    run = engine.Run(torch.device("cuda"), save=False)
+    wd, dyd = dev(w.detach()), dev(dy)
+    dx = torch.full((N, Cin, *dims), float("nan"), device="cuda")
+    for pg, k0, nk, step in phases:
+        ops.conv_fwd(pg, dyd, run.pack(wd, True, taps=nk, tap_base=k0, tap_step=step), dx)
+    close(dx, x.grad, what="phase dgrad")
+    for pg, k0, nk, step in phases:
+        ops.conv_fwd(pg, dyd, run.pack(wd, True, taps=nk, tap_base=k0, tap_step=step), dx,
+                     accumulate=True)
+    close(dx, 2 * x.grad, what="phase dgrad accumulate")
+    # geometries outside the supported form fall back to the dilated formulation
+    assert ops.ConvGeom(2, 8, 8, (4, 14, 14), (1, 3, 3), (1, 2, 2), (0, 1, 1)).dgrad_phases() is None
+    assert ops.ConvGeom(2, 8, 8, (4, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0)).dgrad_phases() is None
+
+
 def test_conv_channel_slices_gather_and_epilogue():
     """x read from a wider buffer through n_index; y accumulated; fused affine+ReLU."""
     from coclr_amd import ops, engine
