@@ -228,9 +228,12 @@ constexpr int kTileFloats = 16384;   // 64 KiB of LDS per workgroup
 
 // planes per workgroup so that the tile is <= kTileFloats and there are enough workgroups
 inline int pick_group(int planes, int Si) {
-  int G = kTileFloats / Si;
-  if (G < 1) return 0;
-  while (G > 1 && (planes + G - 1) / G < 1024) G >>= 1;
+  if (Si > kTileFloats) return 0;
+  // ~16 KiB tiles: 8 workgroups per CU so the load, scan and store phases of different
+  // workgroups overlap (64 KiB tiles left 2 per CU and ran at 1.2 TB/s)
+  int G = 4096 / Si;
+  if (G < 1) G = 1;
+  while (G > 1 && (planes + G - 1) / G < 2048) G >>= 1;
   return G;
 }
 

@@ -236,6 +236,48 @@ class InfoNCE(nn.Module):
         self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
         self._momentum_table = None
 
+    # -- buffers: one flat allocation, one broadcast --------------------------------
+    @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        """DistributedDataParallel skips the buffers named here (it reads this attribute at
+        wrap time).  The model keeps ALL its buffers (BN statistics of three encoders, the
+        queues, the pointer) as views of one flat allocation and broadcasts that from rank 0
+        itself at the start of every forward -- the semantics of the reference's
+        DDP(broadcast_buffers=True) (main_nce.py:172) as ONE
+        collective instead of ~470 tensor copies into and out of a coalescing buffer."""
+        return [n for n, _ in self.named_buffers()]
+
+    def _flatten_buffers(self):
+        seen, entries = set(), []
+        for mod in self.modules():
+            for key, b in mod._buffers.items():
+                if b is not None and id(b) not in seen:
+                    seen.add(id(b))
+                    entries.append((mod, key, b))
+        offs, total = [], 0
+        for _, _, b in entries:
+            offs.append(total)
+            total += (b.numel() * b.element_size() + 15) // 16 * 16
+        flat = torch.empty(total, dtype=torch.uint8, device=self.queue.device)
+        with torch.no_grad():
+            for (mod, key, b), off in zip(entries, offs):
+                v = flat[off:off + b.numel() * b.element_size()].view(b.dtype).view(b.shape)
+                v.copy_(b)
+                mod._buffers[key] = v
+        self.__dict__["_flat_buffers"] = flat
+
+    def _sync_buffers(self):
+        flat = self.__dict__.get("_flat_buffers")
+        if flat is None or flat.device != self.queue.device or \
+                self.queue.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr() or \
+                self.queue_ptr.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
+            self._flatten_buffers()       # first use, or .cuda()/.to() re-created the buffers
+            flat = self.__dict__["_flat_buffers"]
+        world, _ = _world()
+        if world > 1:
+            with torch.no_grad():
+                dist.broadcast(flat, src=0)
+
     # -- momentum encoder ---------------------------------------------------------
     def _build_momentum_table(self):
         rows, sig = [], []
@@ -342,6 +384,7 @@ class InfoNCE(nn.Module):
 
     def forward(self, block):
         '''Output: logits, targets'''
+        self._sync_buffers()
         x1, x2 = self._split_pair(block)
         B = x1.shape[0]
 
@@ -379,6 +422,7 @@ class UberNCE(InfoNCE):
 
     def forward(self, block, k_label):
         '''Output: logits, binary mask for positive pairs'''
+        self._sync_buffers()
         x1, x2 = self._split_pair(block)
         B = x1.shape[0]
 
@@ -441,6 +485,7 @@ class CoCLR(InfoNCE):
 
     def forward(self, block1, block2, k_vsource):
         '''Output: logits, targets'''
+        self._sync_buffers()
         x1, f1 = self._split_pair(block1)
         x2, f2 = self._split_pair(block2)
         if self.reverse:
