@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -34,16 +34,16 @@ _P = C.POINTER
 _SIGNATURES = {
     "coclr_abi_version": [],
     "coclr_conv_packed_size": [i32, i32, i32, i32, _P(i64)],
-    "coclr_conv_pack_weights": [vp, vp, i32, i32, i32, i64, i64, i32, i32, i32, vp],
+    "coclr_conv_pack_weights": [vp, vp, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp],
     "coclr_conv3d_ntiles": [_P(ConvDesc), _P(i32)],
     "coclr_conv3d_fwd": [_P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "coclr_conv3d_wgrad_workspace": [_P(ConvDesc), _P(i64)],
     "coclr_conv3d_wgrad": [_P(ConvDesc), vp, vp, vp, vp, i64, i64, i32, i32, vp],
-    "coclr_bn_finalize": [vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp],
+    "coclr_bn_finalize": [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp],
     "coclr_bn_eval_affine": [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp],
-    "coclr_bn_act_apply": [vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i32, vp],
+    "coclr_bn_act_apply": [vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i64, i32, vp],
     "coclr_bn_act_backward": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64,
-                              i64, i64, i64, i32, i32, i32, vp],
+                              i64, i64, i64, i64, i64, i32, i32, i32, vp],
     "coclr_maxpool3d_fwd": [_P(PoolDesc), vp, vp, vp, vp],
     "coclr_maxpool3d_bwd": [_P(PoolDesc), vp, vp, vp, i64, i64, i32, vp],
     "coclr_global_avgpool_fwd": [vp, vp, i64, i64, vp],

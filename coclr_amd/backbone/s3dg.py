@@ -141,19 +141,27 @@ class SepInception(_Emitter):
             self.gating_b3 = SelfGating(b3b)
 
     def _emit(self, run, x):
-        branches = (self.branch0, self.branch1, self.branch2, self.branch3)
         N, _, T, H, W = x.shape
         odim = (T, H, W)          # every branch preserves the extent
         block = run.empty(N, self.out_channels, *odim)
-        c0 = 0
-        for i, (br, width) in enumerate(zip(branches, self._widths)):
-            dst = engine.Val(block, c0, width)
-            if self.gating:
-                y = br._emit(run, x)
-                getattr(self, "gating_b%d" % i)._emit(run, y, out=dst)
-            else:
-                br._emit(run, x, out=dst)
+        dst, c0 = [], 0
+        for width in self._widths:
+            dst.append(engine.Val(block, c0, width))
             c0 += width
+        # the three 1x1x1 heads read the same x: one convolution over concatenated channels
+        b0, b1a, b2a = self.branch0[0], self.branch1[0], self.branch2[0]
+        heads = engine.pointwise_group(run, x, [(b0.conv, b0.bn, None if self.gating else dst[0]),
+                                                (b1a.conv, b1a.bn, None), (b2a.conv, b2a.bn, None)])
+        tails = (None, self.branch1[1], self.branch2[1])
+        for i in range(4):
+            if i == 3:
+                y = self.branch3._emit(run, x, out=None if self.gating else dst[3])
+            elif tails[i] is not None:
+                y = tails[i]._emit(run, heads[i], out=None if self.gating else dst[i])
+            else:
+                y = heads[0]
+            if self.gating:
+                getattr(self, "gating_b%d" % i)._emit(run, y, out=dst[i])
         return engine.Val(block)
 
 

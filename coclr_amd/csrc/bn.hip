@@ -17,15 +17,16 @@ namespace {
 // One block per channel: fold [2][C][ntiles] partial sums, emit mean / invstd /
 // fused scale+shift, update running stats (unbiased var), bump num_batches_tracked.
 __global__ void __launch_bounds__(256)
-bn_finalize_kernel(const float* __restrict__ stats, int C, int ntiles, double count,
+bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int C,
+                   int ntiles, double count,
                    const float* __restrict__ gamma, const float* __restrict__ beta,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
                    float momentum, float eps, float* mean_out, float* invstd_out,
                    float* scale_out, float* shift_out) {
   __shared__ double red[4];
   const int c = blockIdx.x;
-  const float* ps = stats + (long)c * ntiles;
-  const float* pq = stats + ((long)C + c) * ntiles;
+  const float* ps = sum + (long)c * ntiles;
+  const float* pq = sumsq + (long)c * ntiles;
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < ntiles; i += 256) { s += (double)ps[i]; q += (double)pq[i]; }
   s = block256_sum_d(s, red);
@@ -71,12 +72,13 @@ template <bool VEC>
 __global__ void __launch_bounds__(256)
 bn_act_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ res, float* z,
-                    int N, int C, int S, long z_nstride, long res_nstride, int relu) {
+                    int N, int C, int S, long y_nstride, long z_nstride, long res_nstride,
+                    int relu) {
   const int planes = N * C;
   for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
     const int n = pl / C, c = pl - n * C;
     const float sc = scale[c], sf = shift[c];
-    const float* yp = y + (long)pl * S;
+    const float* yp = y + (long)n * y_nstride + (long)c * S;
     float* zp = z + (long)n * z_nstride + (long)c * S;
     const float* rp = res ? res + (long)n * res_nstride + (long)c * S : nullptr;
     if (VEC) {
@@ -116,14 +118,14 @@ bn_act_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__
                          const float* __restrict__ z, const float* __restrict__ scale,
                          const float* __restrict__ shift, const float* __restrict__ mean,
                          const float* __restrict__ invstd, double* sums, int N, int C, int S,
-                         long dz_nstride, long z_nstride, int relu) {
+                         long dz_nstride, long y_nstride, long z_nstride, int relu) {
   __shared__ double red[4];
   const int c = blockIdx.x;
   const float sc = scale[c], sf = shift[c], mu = mean[c], is = invstd[c];
   double sg = 0.0, sgx = 0.0;
   for (int n = blockIdx.y; n < N; n += gridDim.y) {
     const float* dzp = dz + (long)n * dz_nstride + (long)c * S;
-    const float* yp = y + ((long)n * C + c) * S;
+    const float* yp = y + (long)n * y_nstride + (long)c * S;
     const float* zp = z ? z + (long)n * z_nstride + (long)c * S : nullptr;
     float ag = 0.f, agx = 0.f;
     if (VEC) {
@@ -195,17 +197,18 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
                         const float* __restrict__ z, const float* __restrict__ scale,
                         const float* __restrict__ shift, const float* __restrict__ coefA,
                         const float* __restrict__ coefB, const float* __restrict__ coefD, float* dy,
-                        float* dres, int N, int C, int S, long dz_nstride, long z_nstride,
-                        long dres_nstride, int relu, int dres_accumulate) {
+                        float* dres, int N, int C, int S, long dz_nstride, long y_nstride,
+                        long dy_nstride, long z_nstride, long dres_nstride, int relu,
+                        int dres_accumulate) {
   const int planes = N * C;
   for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
     const int n = pl / C, c = pl - n * C;
     const float sc = scale[c], sf = shift[c];
     const float A = coefA[c], B = coefB[c], D = coefD[c];
     const float* dzp = dz + (long)n * dz_nstride + (long)c * S;
-    const float* yp = y + (long)pl * S;
+    const float* yp = y + (long)n * y_nstride + (long)c * S;
     const float* zp = z ? z + (long)n * z_nstride + (long)c * S : nullptr;
-    float* dyp = dy + (long)pl * S;
+    float* dyp = dy + (long)n * dy_nstride + (long)c * S;
     float* drp = dres ? dres + (long)n * dres_nstride + (long)c * S : nullptr;
     if (VEC) {
       const int S4 = S >> 2;
@@ -262,13 +265,13 @@ inline dim3 plane_grid(int planes, int S) {
 
 }  // namespace
 
-extern "C" int coclr_bn_finalize(const float* stats, int C, int ntiles, double count,
-                                 const float* gamma, const float* beta, float* running_mean,
-                                 float* running_var, int64_t* num_batches_tracked, float momentum,
-                                 float eps, float* mean, float* invstd, float* scale, float* shift,
-                                 void* stream) {
+extern "C" int coclr_bn_finalize(const float* sum, const float* sumsq, int C, int ntiles,
+                                 double count, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float momentum, float eps, float* mean,
+                                 float* invstd, float* scale, float* shift, void* stream) {
   if (C <= 0 || ntiles <= 0) return COCLR_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, sum, sumsq, C,
                      ntiles, count, gamma, beta, running_mean, running_var, num_batches_tracked,
                      momentum, eps, mean, invstd, scale, shift);
   COCLR_LAUNCH_CHECK();
@@ -287,16 +290,20 @@ extern "C" int coclr_bn_eval_affine(const float* gamma, const float* beta, const
 
 extern "C" int coclr_bn_act_apply(const float* y, const float* scale, const float* shift,
                                   const float* residual, float* z, int N, int C, int64_t S,
-                                  int64_t z_nstride, int64_t res_nstride, int relu, void* stream) {
+                                  int64_t y_nstride, int64_t z_nstride, int64_t res_nstride,
+                                  int relu, void* stream) {
   if (N <= 0 || C <= 0 || S <= 0) return COCLR_EINVAL;
-  const bool vec = (S % 4 == 0) && (z_nstride % 4 == 0) && (!residual || res_nstride % 4 == 0);
+  const bool vec = (S % 4 == 0) && (y_nstride % 4 == 0) && (z_nstride % 4 == 0) &&
+                   (!residual || res_nstride % 4 == 0);
   dim3 grid = plane_grid(N * C, (int)S);
   if (vec)
     hipLaunchKernelGGL(bn_act_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, scale,
-                       shift, residual, z, N, C, (int)S, (long)z_nstride, (long)res_nstride, relu);
+                       shift, residual, z, N, C, (int)S, (long)y_nstride, (long)z_nstride,
+                       (long)res_nstride, relu);
   else
     hipLaunchKernelGGL(bn_act_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y, scale,
-                       shift, residual, z, N, C, (int)S, (long)z_nstride, (long)res_nstride, relu);
+                       shift, residual, z, N, C, (int)S, (long)y_nstride, (long)z_nstride,
+                       (long)res_nstride, relu);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
@@ -305,12 +312,13 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
                                      const float* scale, const float* shift, const float* mean,
                                      const float* invstd, double* sums_ws, float* coef_ws, float* dy,
                                      float* dres, float* dgamma, float* dbeta, int N, int C,
-                                     int64_t S, int64_t dz_nstride, int64_t z_nstride,
-                                     int64_t dres_nstride, int relu, int training,
-                                     int dres_accumulate, void* stream_) {
+                                     int64_t S, int64_t dz_nstride, int64_t y_nstride,
+                                     int64_t dy_nstride, int64_t z_nstride, int64_t dres_nstride,
+                                     int relu, int training, int dres_accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N <= 0 || C <= 0 || S <= 0) return COCLR_EINVAL;
-  const bool vec = (S % 4 == 0) && (dz_nstride % 4 == 0) && (!z || z_nstride % 4 == 0) &&
+  const bool vec = (S % 4 == 0) && (dz_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
+                   (dy_nstride % 4 == 0) && (!z || z_nstride % 4 == 0) &&
                    (!dres || dres_nstride % 4 == 0);
   COCLR_RETURN_IF(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, stream));
   int gy = N;
@@ -319,11 +327,11 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
   if (vec)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, stream, dz, y, z, scale,
                        shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride,
-                       (long)z_nstride, relu);
+                       (long)y_nstride, (long)z_nstride, relu);
   else
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, stream, dz, y, z,
                        scale, shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride,
-                       (long)z_nstride, relu);
+                       (long)y_nstride, (long)z_nstride, relu);
   COCLR_LAUNCH_CHECK();
   float* coefA = coef_ws;
   float* coefB = coef_ws + C;
@@ -336,11 +344,13 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
   if (vec)
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, grid, dim3(256), 0, stream, dz, y, z, scale,
                        shift, coefA, coefB, coefD, dy, dres, N, C, (int)S, (long)dz_nstride,
-                       (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
+                       (long)y_nstride, (long)dy_nstride, (long)z_nstride, (long)dres_nstride, relu,
+                       dres_accumulate);
   else
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, grid, dim3(256), 0, stream, dz, y, z, scale,
                        shift, coefA, coefB, coefD, dy, dres, N, C, (int)S, (long)dz_nstride,
-                       (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
+                       (long)y_nstride, (long)dy_nstride, (long)z_nstride, (long)dres_nstride, relu,
+                       dres_accumulate);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

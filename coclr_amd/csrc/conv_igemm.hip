@@ -350,14 +350,17 @@ conv_igemm_kernel(const ConvArgs a) {
 //   dgrad   : r = cout, c = cin,  src tap = tap_base + (taps-1-tap)*tap_step (stencil flipped)
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst,
                                     int Cout, int Cin, int taps, long co_stride, long ci_stride,
-                                    int tap_base, int tap_step, int RP, int CP, int transpose) {
-  const long total = (long)taps * RP * CP;
+                                    int tap_base, int tap_step, int RP, int CP, int transpose,
+                                    int row0, int col0, int rows, int cols) {
+  // (rows, cols) = extent written per tap: the padded operand when it stands alone, only the
+  // real sub-block when it is placed inside a wider (pre-zeroed) operand
+  const long total = (long)taps * rows * cols;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % CP);
-    const long q = e / CP;
-    const int rr = (int)(q % RP);
-    const int tap = (int)(q / RP);
+    const int c = (int)(e % cols);
+    const long q = e / cols;
+    const int rr = (int)(q % rows);
+    const int tap = (int)(q / rows);
     float v = 0.f;
     if (!transpose) {
       if (rr < Cin && c < Cout) v = w[c * co_stride + rr * ci_stride + tap_base + tap * tap_step];
@@ -365,7 +368,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
       if (rr < Cout && c < Cin)
         v = w[rr * co_stride + c * ci_stride + tap_base + (taps - 1 - tap) * tap_step];
     }
-    dst[e] = v;
+    dst[((long)tap * RP + row0 + rr) * CP + col0 + c] = v;
   }
 }
 
@@ -431,15 +434,20 @@ extern "C" int coclr_conv_packed_size(int cin, int cout, int taps, int transpose
 
 extern "C" int coclr_conv_pack_weights(const float* w, float* packed, int cout, int cin, int taps,
                                        int64_t co_stride, int64_t ci_stride, int tap_base,
-                                       int tap_step, int transpose, void* stream) {
+                                       int tap_step, int transpose, int row0, int rows_total,
+                                       int col0, int cols_total, void* stream) {
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
-  const int RP = pad_to(r, 32), CP = pad_to(c, 128);
-  const long total = (long)taps * RP * CP;
+  const bool placed = rows_total > 0 && cols_total > 0;
+  if (placed && (row0 < 0 || col0 < 0 || row0 + r > rows_total || col0 + c > cols_total))
+    return COCLR_EINVAL;
+  const int RP = pad_to(placed ? rows_total : r, 32), CP = pad_to(placed ? cols_total : c, 128);
+  const int rows = placed ? r : RP, cols = placed ? c : CP;
+  const long total = (long)taps * rows * cols;
   int blocks = cdiv(total, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
                      packed, cout, cin, taps, (long)co_stride, (long)ci_stride, tap_base, tap_step,
-                     RP, CP, transpose);
+                     RP, CP, transpose, placed ? row0 : 0, placed ? col0 : 0, rows, cols);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

@@ -113,6 +113,25 @@ class Run:
                               transpose, tap_step)
         return packed
 
+    def pack_concat(self, weights, transpose):
+        """Pointwise weights [Cout_i][Cin] of convs sharing one input, as ONE packed operand over
+        the concatenated output channels (forward) / reduction rows (data gradient)."""
+        cin = weights[0].shape[1]
+        ctot = sum(w.shape[0] for w in weights)
+        n = ops.conv_packed_size(cin, ctot, 1, transpose)
+        packed = torch.zeros(n, dtype=torch.float32, device=self.device)
+        c0 = 0
+        for w in weights:
+            cout = w.shape[0]
+            if transpose:
+                ops.conv_pack_weights(w, packed, cout, cin, 1, cin, 1, 0, True, 1,
+                                      row0=c0, rows_total=ctot, col0=0, cols_total=cin)
+            else:
+                ops.conv_pack_weights(w, packed, cout, cin, 1, cin, 1, 0, False, 1,
+                                      row0=0, rows_total=cin, col0=c0, cols_total=ctot)
+            c0 += cout
+        return packed
+
 
 # ---------------------------------------------------------------------------------
 # conv (+ BatchNorm) (+ residual) (+ ReLU)
@@ -244,6 +263,92 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
     elif y is not None:
         del y
     return out
+
+
+FUSE_POINTWISE = True     # debugging switch: False runs the units of a group one by one
+
+
+def pointwise_group(run, x, units):
+    """Several 1x1x1 conv+BN+ReLU units that read the SAME input -- the heads of an inception
+    block, branch0 / branch1[0] / branch2[0] (backbone/s3dg.py:97-104,119-123) -- executed as
+    one convolution over their concatenated output channels: one pass over x instead of
+    three, one weight-gradient GEMM, and one data-gradient GEMM that writes dX once
+    instead of three read-modify-write passes.
+
+    units: [(conv, bn, out Val or None)]; returns the activations as Vals.
+    Falls back to separate launches when statistics are frozen and nothing is saved
+    (BN+ReLU then fold into each conv's epilogue)."""
+    training = all(bn.training or bn.running_mean is None for _, bn, _ in units)
+    if not (training or run.save) or len(units) == 1 or not FUSE_POINTWISE:
+        return [conv_bn_act(run, x, conv, bn, relu=True, out=out) for conv, bn, out in units]
+    for conv, bn, _ in units:
+        if tuple(conv.weight.shape[2:]) != (1, 1, 1) or _triple(conv.stride) != (1, 1, 1) or \
+                _triple(conv.padding) != (0, 0, 0) or conv.bias is not None or \
+                (bn.training or bn.running_mean is None) != training:
+            raise NotImplementedError("coclr_amd: pointwise_group takes plain 1x1x1 conv units")
+    N, Cin, idim = x.shape[0], x.shape[1], x.shape[2:]
+    widths = [conv.weight.shape[0] for conv, _, _ in units]
+    Ccat = sum(widths)
+    weights = [conv.weight for conv, _, _ in units]
+    geom = ops.ConvGeom(N, Cin, Ccat, idim, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    xv = x.view()
+    y = run.empty(N, Ccat, *idim)
+    ntiles = geom.ntiles()
+    stats = run.empty(2 * Ccat * ntiles) if training else None
+    ops.conv_fwd(geom, xv, run.pack_concat(weights, False), y, stats=stats)
+    count = N * idim[0] * idim[1] * idim[2]
+    outs, saved = [], []
+    c0 = 0
+    for (conv, bn, out), C_ in zip(units, widths):
+        small = run.empty(4, C_)
+        mean, invstd, scale, shift = small[0], small[1], small[2], small[3]
+        if training:
+            if bn.momentum is None:
+                raise NotImplementedError("coclr_amd: cumulative-average BatchNorm momentum")
+            ops.bn_finalize(stats, C_, ntiles, count, bn.weight, bn.bias, bn.running_mean,
+                            bn.running_var, bn.num_batches_tracked, float(bn.momentum),
+                            float(bn.eps), mean, invstd, scale, shift, c0=c0, c_total=Ccat)
+        else:
+            ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                               C_, mean, invstd, scale, shift)
+        if out is None:
+            out = Val(run.empty(N, C_, *idim))
+        ops.bn_act_apply(y[:, c0:c0 + C_], scale, shift, None, out.view(), True)
+        outs.append(out)
+        saved.append((c0, C_, mean, invstd, scale, shift))
+        c0 += C_
+
+    if run.save:
+        x_needs = run.needs_grad(x)
+
+        def backward():
+            dy = torch.empty_like(y)
+            for (conv, bn, _), out, (c0, C_, mean, invstd, scale, shift) in zip(units, outs, saved):
+                dgb = run.empty(2, C_)
+                sums = run.empty(2 * C_, dtype=torch.float64)
+                coef = run.empty(3 * C_)
+                ops.bn_act_backward(run.grad_of(out), y[:, c0:c0 + C_], None, scale, shift, mean,
+                                    invstd, sums, coef, dy[:, c0:c0 + C_], None, dgb[0], dgb[1],
+                                    True, training)
+                if bn.weight.requires_grad:
+                    run.add_param_grad(bn.weight, dgb[0])
+                if bn.bias.requires_grad:
+                    run.add_param_grad(bn.bias, dgb[1])
+            if any(w.requires_grad for w in weights):
+                dw = run.empty(Ccat, Cin, 1, 1, 1)
+                ws = run.empty(geom.wgrad_workspace())
+                ops.conv_wgrad(geom, xv, dy, dw, ws, Cin, 1, 0)
+                c0 = 0
+                for w in weights:
+                    if w.requires_grad:
+                        run.add_param_grad(w, dw[c0:c0 + w.shape[0]])
+                    c0 += w.shape[0]
+            if x_needs:
+                dx, acc = run.grad_target(x)
+                ops.conv_fwd(geom.dgrad(), dy, run.pack_concat(weights, True), dx, accumulate=acc)
+
+        run.tape.append(backward)
+    return outs
 
 
 # ---------------------------------------------------------------------------------

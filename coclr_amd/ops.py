@@ -161,10 +161,10 @@ def conv_packed_size(cin, cout, taps, transpose):
 
 
 def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose,
-                      tap_step=1):
+                      tap_step=1, row0=0, rows_total=0, col0=0, cols_total=0):
     _lib.check(_lib.load().coclr_conv_pack_weights(
         _p(w), _p(packed), cout, cin, taps, co_stride, ci_stride, tap_base, tap_step,
-        int(transpose), _stream()), "conv_pack_weights")
+        int(transpose), row0, rows_total, col0, cols_total, _stream()), "conv_pack_weights")
 
 
 def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shift=None,
@@ -190,11 +190,15 @@ def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accum
 # ---- batch norm ------------------------------------------------------------------
 
 def bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt, momentum,
-                eps, mean, invstd, scale, shift):
+                eps, mean, invstd, scale, shift, c0=0, c_total=None):
+    """stats: [2][c_total][ntiles] partial sums of a convolution with c_total output channels;
+    this call finalises channels [c0, c0+C_)."""
+    c_total = C_ if c_total is None else c_total
+    base = _p(stats)
     _lib.check(_lib.load().coclr_bn_finalize(
-        _p(stats), C_, ntiles, float(count), _p(gamma), _p(beta), _p(running_mean),
-        _p(running_var), _p(nbt, torch.int64), momentum, eps, _p(mean), _p(invstd), _p(scale),
-        _p(shift), _stream()), "bn_finalize")
+        base + 4 * c0 * ntiles, base + 4 * (c_total + c0) * ntiles, C_, ntiles, float(count),
+        _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(nbt, torch.int64), momentum, eps,
+        _p(mean), _p(invstd), _p(scale), _p(shift), _stream()), "bn_finalize")
 
 
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps, C_, mean, invstd, scale, shift):
@@ -206,10 +210,8 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps, C_, mean, invstd
 def bn_act_apply(y, scale, shift, residual, z, relu):
     N, C_, T, H, W = y.shape
     S = T * H * W
-    if not y.is_contiguous():
-        raise ValueError("coclr_amd: bn_act_apply expects contiguous y")
     _lib.check(_lib.load().coclr_bn_act_apply(
-        _p(y), _p(scale), _p(shift), _p(residual), _p(z), N, C_, S, _chk5(z, "z"),
+        _p(y), _p(scale), _p(shift), _p(residual), _p(z), N, C_, S, _chk5(y, "y"), _chk5(z, "z"),
         _chk5(residual, "residual") if residual is not None else 0, int(relu), _stream()),
         "bn_act_apply")
 
@@ -218,12 +220,10 @@ def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, coef_ws, dy, 
                     dbeta, relu, training, dres_accumulate=False):
     N, C_, T, H, W = y.shape
     S = T * H * W
-    if not (y.is_contiguous() and dy.is_contiguous()):
-        raise ValueError("coclr_amd: bn_act_backward expects contiguous y/dy")
     _lib.check(_lib.load().coclr_bn_act_backward(
         _p(dz), _p(y), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd),
         _p(sums_ws, torch.float64), _p(coef_ws), _p(dy), _p(dres), _p(dgamma), _p(dbeta), N, C_, S,
-        _chk5(dz, "dz"), _chk5(z, "z") if z is not None else 0,
+        _chk5(dz, "dz"), _chk5(y, "y"), _chk5(dy, "dy"), _chk5(z, "z") if z is not None else 0,
         _chk5(dres, "dres") if dres is not None else 0, int(relu), int(training),
         int(dres_accumulate), _stream()), "bn_act_backward")
 

@@ -58,16 +58,20 @@ typedef struct coclr_conv_desc {
 /* Number of fp32 elements of the packed-weight buffer for one conv. */
 int coclr_conv_packed_size(int cin, int cout, int taps, int transpose, int64_t* elems);
 
-/* Re-lay [Cout][Cin][taps] weights as [taps][Cin'][Cout'] (zero padded: reduction
- * channels to x32, produced channels to x128).
- * transpose=0: operand of the forward conv; transpose=1: operand of the data
- * gradient (roles of Cin/Cout swapped, stencil flipped).  co/ci strides, tap_base
- * and tap_step address a sub-stencil: source tap of packed tap t is
- * tap_base + t*tap_step (one kt-slice of a (5,7,7) stem; the taps of one phase of a
- * strided data gradient). */
+/* Re-lay [Cout][Cin][taps] weights as [taps][R'][C'] (zero padded: reduction
+ * channels R to x32, produced channels C to x128).
+ * transpose=0: operand of the forward conv (R = Cin, C = Cout); transpose=1: operand of
+ * the data gradient (R = Cout, C = Cin, stencil flipped).  co/ci strides, tap_base and
+ * tap_step address a sub-stencil: source tap of packed tap t is tap_base + t*tap_step
+ * (one kt-slice of a (5,7,7) stem; the taps of one phase of a strided data gradient).
+ * rows_total/cols_total > 0 place this tensor at (row0, col0) of a WIDER packed operand
+ * [taps][pad32(rows_total)][pad128(cols_total)] that the caller has zero-filled: several
+ * convs that read the same input (the three 1x1x1 heads of an inception block,
+ * backbone/s3dg.py:97-112) then run as one convolution over concatenated channels. */
 int coclr_conv_pack_weights(const float* w, float* packed, int cout, int cin, int taps,
                             int64_t co_stride, int64_t ci_stride, int tap_base, int tap_step,
-                            int transpose, void* stream);
+                            int transpose, int row0, int rows_total, int col0, int cols_total,
+                            void* stream);
 
 /* Number of per-workgroup BatchNorm partial sums coclr_conv3d_fwd will emit
  * per channel for this geometry (stats buffer = 2 * Cout * ntiles floats). */
@@ -100,24 +104,26 @@ int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, const float* dy
 /*                                   60-64; backbone/resnet_2d3d.py:54-83)   */
 /* ------------------------------------------------------------------------ */
 
-/* Fold the conv partial sums: batch mean / invstd, fused scale = gamma*invstd
- * and shift = beta - mean*scale; momentum update of running_mean /
- * running_var (unbiased) and num_batches_tracked += 1 (aten::batch_norm,
+/* Fold the conv partial sums (sum[c][ntiles], sumsq[c][ntiles]; two pointers so a channel
+ * range of a concatenated convolution can be finalised on its own): batch mean / invstd,
+ * fused scale = gamma*invstd and shift = beta - mean*scale; momentum update of
+ * running_mean / running_var (unbiased) and num_batches_tracked += 1 (aten::batch_norm,
  * training=True). */
-int coclr_bn_finalize(const float* stats, int C, int ntiles, double count, const float* gamma,
-                      const float* beta, float* running_mean, float* running_var,
-                      int64_t* num_batches_tracked, float momentum, float eps, float* mean,
-                      float* invstd, float* scale, float* shift, void* stream);
+int coclr_bn_finalize(const float* sum, const float* sumsq, int C, int ntiles, double count,
+                      const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                      float* mean, float* invstd, float* scale, float* shift, void* stream);
 
 /* Eval-mode coefficients from the running statistics (main_coclr.py:363). */
 int coclr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* mean, float* invstd,
                          float* scale, float* shift, void* stream);
 
-/* z = act(y*scale[c] + shift[c] (+ residual)); y contiguous [N][C][S]. */
+/* z = act(y*scale[c] + shift[c] (+ residual)); every tensor is [N][C][S] with its own
+ * sample stride (channel slices of wider buffers). */
 int coclr_bn_act_apply(const float* y, const float* scale, const float* shift,
-                       const float* residual, float* z, int N, int C, int64_t S, int64_t z_nstride,
-                       int64_t res_nstride, int relu, void* stream);
+                       const float* residual, float* z, int N, int C, int64_t S, int64_t y_nstride,
+                       int64_t z_nstride, int64_t res_nstride, int relu, void* stream);
 
 /* Backward of the above (aten::threshold_backward + native_batch_norm_backward):
  * dy, dgamma, dbeta and, for residual units, dres (+)= masked dz.
@@ -127,8 +133,9 @@ int coclr_bn_act_backward(const float* dz, const float* y, const float* z, const
                           const float* shift, const float* mean, const float* invstd,
                           double* sums_ws, float* coef_ws, float* dy, float* dres, float* dgamma,
                           float* dbeta, int N, int C, int64_t S, int64_t dz_nstride,
-                          int64_t z_nstride, int64_t dres_nstride, int relu, int training,
-                          int dres_accumulate, void* stream);
+                          int64_t y_nstride, int64_t dy_nstride, int64_t z_nstride,
+                          int64_t dres_nstride, int relu, int training, int dres_accumulate,
+                          void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Pooling (backbone/s3dg.py:105,151,162,173,190; resnet_2d3d.py:141;        */

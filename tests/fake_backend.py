@@ -27,16 +27,16 @@ def conv_packed_size(cin, cout, taps, transpose):
 
 
 def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose,
-                      tap_step=1):
+                      tap_step=1, row0=0, rows_total=0, col0=0, cols_total=0):
     w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, taps),
                           (co_stride, ci_stride, tap_step), tap_base)
     r, c = (cout, cin) if transpose else (cin, cout)
-    dst = packed.view(taps, _r32(r), _r128(c))
-    dst.zero_()
-    if transpose:
-        dst[:, :cout, :cin] = w3.flip(2).permute(2, 0, 1)
-    else:
-        dst[:, :cin, :cout] = w3.permute(2, 1, 0)
+    placed = rows_total > 0 and cols_total > 0
+    dst = packed.view(taps, _r32(rows_total if placed else r), _r128(cols_total if placed else c))
+    if not placed:
+        dst.zero_()
+    src = w3.flip(2).permute(2, 0, 1) if transpose else w3.permute(2, 1, 0)
+    dst[:, row0:row0 + r, col0:col0 + c] = src
 
 
 def _unpack(geom, wp):
@@ -115,8 +115,9 @@ def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accum
 
 
 def bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt, momentum,
-                eps, mean, invstd, scale, shift):
-    st = stats.view(2, C_, ntiles).double().sum(-1)
+                eps, mean, invstd, scale, shift, c0=0, c_total=None):
+    c_total = C_ if c_total is None else c_total
+    st = stats.view(2, c_total, ntiles)[:, c0:c0 + C_].double().sum(-1)
     mu = st[0] / count
     var = (st[1] / count - mu * mu).clamp_min(0)
     inv = 1.0 / torch.sqrt(var + eps)
