@@ -15,7 +15,8 @@ struct ConvPlan {
   // box: log2 extents (w, h, t, n), number of boxes per axis
   int lTW, lTH, lTT, lTN;
   int nbw, nbh, nbt, nbn;
-  int ntiles;
+  int ntiles;   // partial-statistics slots a forward launch emits per channel
+  int nboxes;   // boxes covering the output
   // per-sample window extents and sizes
   int WT, WH, WW, plane1, plane;
 };
@@ -71,6 +72,7 @@ static inline void conv_pick_box(ConvPlan* p, int lbn, int kt, int kh, int kw) {
   p->nbt = cdiv(p->To, 1 << lt);
   p->nbn = cdiv(p->N, 1 << ln);
   p->ntiles = p->nbw * p->nbh * p->nbt * p->nbn;
+  p->nboxes = p->ntiles;
   p->WT = ((1 << lt) - 1) * p->st + kt;
   p->WH = ((1 << lh) - 1) * p->sh + kh;
   p->WW = ((1 << lw) - 1) * p->sw + kw;

@@ -344,6 +344,335 @@ conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Stem kernel: spatial (1,KH,KW) stencil over a handful of input channels (Cin = 3:
+// backbone/s3dg.py:145 Conv_1a.conv1, and the five slices of resnet_2d3d.py:138).
+//
+// With Cin = 3 the whole reduction is K = 3*49 = 147 products: the chunked kernel above
+// would pad it to 4 channels (25 % of the MFMAs multiply zeros) and reload the 50 KB weight
+// tile for every 128 output positions.  Here instead
+//   * the workgroup is PERSISTENT: the [K][64] weight tile is DMA'd into LDS once and stays,
+//     a grid of <= 512 workgroups walks the boxes;
+//   * K runs over (channel, kh, kw padded to 8): an MFMA step multiplies two neighbouring kw of
+//     one stencil row (12.5 % zero work instead of 25 %), every operand read is base+immediate;
+//   * the input window of box b+1 streams in through the LDS-DMA engine while box b is
+//     multiplied (two window stages, one barrier per box);
+//   * BatchNorm partial sums are carried in registers across boxes: one partial per
+//     workgroup instead of one per box.
+template <int KH, int KW, int CIN, int PCH>
+__global__ void __launch_bounds__(256)
+conv_stem_kernel(const ConvArgs a, const int nboxes) {
+  // reduction index k = (c, kh, slot): KWP slots per stencil row (kw padded to even; the pad
+  // slot has zero weights), so MFMA step (row, q) multiplies slots 2q / 2q+1 and every LDS
+  // read of a row is `base + immediate`.
+  constexpr int TAPS = KH * KW, KWP = (KW + 1) & ~1, QS = KWP / 2;
+  constexpr int NROWS = CIN * KH, KROWS = NROWS * KWP, KSTEPS = NROWS * QS;
+  constexpr int BM = 64, BN = 128, NF = 2;
+  constexpr int W_FLOATS = ((KROWS * BM + 255) / 256) * 256;
+  constexpr int WPIECES = W_FLOATS / 256;
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeS = a.planeS;
+  const int xstage = CIN * planeS;
+  float* Ws = smem;
+  float* Xs0 = smem + W_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int cout0 = blockIdx.y * BM;
+  const int plane = a.plane;
+  const bool gather = a.n_index != nullptr;
+
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
+
+  // ---- weights, once: LDS row (c, kh, slot) <- packed row (tap*CinP + c), pad slot = 0 ----
+  for (int p = wave; p < WPIECES; p += 4) {
+    const int row = p * 4 + (lane >> 4);
+    const int c = row / (KH * KWP), r2 = row - c * (KH * KWP);
+    const int kh = r2 / KWP, slot = r2 - kh * KWP;
+    const int tap = kh * KW + slot;
+    const unsigned voff =
+        (row < KROWS && slot < KW)
+            ? (unsigned)((((long)tap * a.CinP + c) * a.CoutP + cout0 + (lane & 15) * 4) * 4)
+            : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(Ws + p * 256), 16, voff, 0, 0, 0);
+  }
+
+  // ---- box-independent part of the window addresses ------------------------------------
+  // The per-box work has to stay tiny (the VALU shares the wave with the MFMA stream):
+  // byte offset of window element e for a box at (vt0, vh0) = pre[e] + vt0*frame + vh0*row
+  // when the box spans the full output width and samples are not gathered ("fast" form);
+  // only the frame / row range checks remain per box.
+  const bool fast = a.nbw == 1 && !gather;
+  const unsigned rowpitch = (unsigned)a.Wi * 4u, framepitch = (unsigned)(a.Hi * a.Wi) * 4u;
+  // wave w moves window pieces w, w+4, w+8, ... (64 elements each) of every channel, so a lane
+  // only ever needs the addresses of PW = PCH/4 elements
+  constexpr int PW = (PCH + 3) / 4;
+  unsigned wcoord[PW];   // wn | wt << 8 | wh << 16 | ww << 24, or ~0 past the window
+  unsigned pre[PW];
+  {
+    const int hw = a.WH * a.WW;
+    const unsigned npitch = (unsigned)a.x_nstride * 4u;
+#pragma unroll
+    for (int jj = 0; jj < PW; ++jj) {
+      const int e = (wave + 4 * jj) * 64 + lane;
+      unsigned v = 0xffffffffu, pr = OOB;
+      if (e < plane) {
+        const int q0 = fdiv(e, a.inv_plane1);
+        int q = e - q0 * a.plane1;
+        const int t = fdiv(q, a.inv_hw); q -= t * hw;
+        const int h = fdiv(q, a.inv_ww);
+        const int w = q - h * a.WW;
+        v = (unsigned)q0 | ((unsigned)t << 8) | ((unsigned)h << 16) | ((unsigned)w << 24);
+        const int iw = w - a.pw;
+        if ((unsigned)iw < (unsigned)a.Wi)
+          pr = (unsigned)iw * 4u + (unsigned)q0 * npitch + (unsigned)t * framepitch +
+               (unsigned)h * rowpitch;
+      }
+      wcoord[jj] = v;
+      pre[jj] = pr;
+    }
+  }
+  // frames can leave the tensor only with temporal padding / overhang; samples only when a box
+  // spans several of them
+  const bool chk_t = a.pt != 0 || (a.nbt << a.lTT) * a.st + (a.WT - 1) - a.pt > a.Ti - 1 + a.st;
+  const bool chk_n = a.lTN != 0;
+
+  // per-lane position inside a box (shared by all boxes)
+  int lanebase[NF];
+  unsigned ylane[NF];
+  int ptw[NF], pth[NF], ptt[NF], ptn[NF];
+  const unsigned half_rows = (unsigned)half * 4u * (unsigned)a.y_cstride * 4u;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BN / 2) + nf * 32 + l31;
+    ptw[nf] = p & ((1 << a.lTW) - 1);
+    pth[nf] = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    ptt[nf] = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    ptn[nf] = p >> (a.lTW + a.lTH + a.lTT);
+    lanebase[nf] = ptn[nf] * a.plane1 + ((ptt[nf] * a.st) * a.WH + pth[nf] * a.sh) * a.WW +
+                   ptw[nf] * a.sw;
+    // destination offset = ylane (position inside the box) + a per-box scalar
+    ylane[nf] = (unsigned)(((long)ptn[nf] * a.y_nstride +
+                            ((long)(ptt[nf] * a.yst) * a.yHf + pth[nf] * a.ysh) * a.yWf +
+                            ptw[nf] * a.ysw) * 4) + half_rows;
+  }
+  const int abase = half * BM + wm * 32 + l31;
+
+  auto box_origin = [&](int box, int& n0, int& ot0, int& oh0, int& ow0) {
+    int r = box;
+    const int bw_ = r % a.nbw; r /= a.nbw;
+    const int bh_ = r % a.nbh; r /= a.nbh;
+    const int bt_ = r % a.nbt; r /= a.nbt;
+    n0 = r << a.lTN; ot0 = bt_ << a.lTT; oh0 = bh_ << a.lTH; ow0 = bw_ << a.lTW;
+  };
+
+  auto stage_x = [&](int box, float* xs) {
+    int n0, ot0, oh0, ow0;
+    box_origin(box, n0, ot0, oh0, ow0);
+    const int vt0 = ot0 * a.st - a.pt, vh0 = oh0 * a.sh - a.ph, vw0 = ow0 * a.sw - a.pw;
+    const float* xbase = gather ? a.x : a.x + (long)n0 * a.x_nstride;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, BUF_RANGE, 0x00020000);
+    unsigned goff[PW];
+    if (fast) {
+      const unsigned sbox = (unsigned)vt0 * framepitch + (unsigned)vh0 * rowpitch;   // mod 2^32
+#pragma unroll
+      for (int jj = 0; jj < PW; ++jj) {
+        const unsigned wc = wcoord[jj];
+        bool ok = (unsigned)(vh0 + (int)((wc >> 16) & 255u)) < (unsigned)a.Hi;
+        if (chk_t) ok = ok && (unsigned)(vt0 + (int)((wc >> 8) & 255u)) < (unsigned)a.Ti;
+        if (chk_n) ok = ok && n0 + (int)(wc & 255u) < a.N;
+        // pre == OOB (padding column / past the window) must stay out of range
+        goff[jj] = (ok && pre[jj] != OOB) ? pre[jj] + sbox : OOB;
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < PW; ++jj) {
+        const unsigned wc = wcoord[jj];
+        const int wn_ = (int)(wc & 255u);
+        const int n = n0 + wn_;
+        const int it = vt0 + (int)((wc >> 8) & 255u);
+        const int ih = vh0 + (int)((wc >> 16) & 255u);
+        const int iw = vw0 + (int)(wc >> 24);
+        const bool ok = wc != 0xffffffffu && n < a.N && (unsigned)it < (unsigned)a.Ti &&
+                        (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+        unsigned off = OOB;
+        if (ok) {
+          const long ns = gather ? (long)a.n_index[n] : (long)wn_;
+          off = (unsigned)((ns * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4);
+        }
+        goff[jj] = off;
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < PW; ++jj) {
+      const int j = wave + 4 * jj;
+      if (j * 64 < plane) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
+                                                   goff[jj],
+                                                   (unsigned)c * (unsigned)a.x_cstride * 4u, 0, 0);
+      }
+    }
+  };
+
+  float st_s[16], st_q[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+
+  int box = blockIdx.x;
+  if (box < nboxes) stage_x(box, Xs0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): my DMA pieces (weights, first box) landed
+  __syncthreads();
+  for (int it = 0; box < nboxes; box += gridDim.x, ++it) {
+    const float* xs = Xs0 + (it & 1) * xstage;
+    if (box + (int)gridDim.x < nboxes) stage_x(box + gridDim.x, Xs0 + ((it + 1) & 1) * xstage);
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
+
+    // Rolled, software-pipelined reduction (a fully unrolled 74-step body is ~50 KB of code
+    // and thrashes the instruction cache): operands of step s+1 and the window offset of
+    // step s+2 are in flight while the MFMAs of step s issue.
+    // fully unrolled, operands fetched TWO steps ahead of the MFMAs that consume them
+    // (rotating register triple buffer; every read is base + immediate)
+    auto fetch = [&](int st, float& av, float (&bv)[NF]) {
+      const int row = st / QS, q = st % QS;
+      const int c = row / KH, kh = row % KH;
+      const int xo = c * planeS + kh * a.WW + 2 * q;          // scalar
+      av = Ws[abase + (row * KWP + 2 * q) * BM];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bv[nf] = xs[lanebase[nf] + half + xo];
+    };
+    float av[3], bv[3][NF];
+    fetch(0, av[0], bv[0]);
+    fetch(1, av[1], bv[1]);
+#pragma unroll
+    for (int st = 0; st < KSTEPS; ++st) {
+      if (st + 2 < KSTEPS) fetch(st + 2, av[(st + 2) % 3], bv[(st + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st % 3], bv[st % 3][nf], acc[nf], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // The window of the next box was requested before the MFMA loop: waiting for it HERE,
+    // before this box's stores are issued, keeps the store latency off the critical path
+    // (vmcnt counts stores too).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue of this box ------------------------------------------------------
+    int n0, ot0, oh0, ow0;
+    box_origin(box, n0, ot0, oh0, ow0);
+    float* ybase = a.y + (long)n0 * a.y_nstride;
+    const __amdgpu_buffer_rsrc_t ry =
+        __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, BUF_RANGE, 0x00020000);
+    const unsigned ybox = (unsigned)((((long)(ot0 * a.yst + a.yot) * a.yHf + (oh0 * a.ysh + a.yoh)) *
+                                          a.yWf + (ow0 * a.ysw + a.yow)) * 4);
+    const bool box_full = n0 + (1 << a.lTN) <= a.N && ot0 + (1 << a.lTT) <= a.To &&
+                          oh0 + (1 << a.lTH) <= a.Ho && ow0 + (1 << a.lTW) <= a.Wo;
+    unsigned yvoff[NF];
+    bool pvalid[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      pvalid[nf] = box_full || (n0 + ptn[nf] < a.N && ot0 + ptt[nf] < a.To &&
+                                oh0 + pth[nf] < a.Ho && ow0 + ptw[nf] < a.Wo);
+      yvoff[nf] = pvalid[nf] ? ylane[nf] + ybox : OOB;
+    }
+    {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * 32 + (i & 3) + 8 * (i >> 2);
+        const int co = cout0 + rowu + 4 * half;
+        const bool cok = co < a.Cout;
+        const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+        float bia = 0.f, sc = 1.f, sf = 0.f;
+        if (a.bias && cok) bia = a.bias[co];
+        if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const unsigned vo = cok ? yvoff[nf] : OOB;
+          float v = acc[nf][i];
+          if (a.accumulate)
+            v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo, soff, 0));
+          const float vm = pvalid[nf] ? v : 0.f;
+          st_s[i] += vm; st_q[i] += vm * vm;
+          v += bia;
+          v = v * sc + sf;
+          if (a.relu) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vo, soff, 0);
+        }
+      }
+    }
+    // every wave's share of the next window has landed (waited above) and every wave is done
+    // reading this one (its MFMAs have issued): a bare barrier, no memory-counter drain
+    asm volatile("s_barrier" ::: "memory");
+  }
+
+  // ---- one BatchNorm partial per workgroup ---------------------------------------------
+  if (a.stats != nullptr) {
+    __syncthreads();
+    float* red = Xs0;   // [4][BM][2]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ml = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      const float s = row16_sum(st_s[i]), q = row16_sum(st_q[i]);
+      if ((lane & 15) == 0) {
+        const int slot = wn * 2 + (l31 >> 4);
+        red[(slot * BM + ml) * 2 + 0] = s;
+        red[(slot * BM + ml) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BM) {
+      const int co = cout0 + tid;
+      if (co < a.Cout) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s += red[(k * BM + tid) * 2]; q += red[(k * BM + tid) * 2 + 1]; }
+        a.stats[(long)co * a.ntiles + blockIdx.x] = s;
+        a.stats[((long)a.Cout + co) * a.ntiles + blockIdx.x] = q;
+      }
+    }
+  }
+}
+
+constexpr int kStemGrid = 512;   // persistent workgroups of the stem kernel (2 per CU)
+
+template <int KH, int KW, int CIN, int PCH>
+int launch_stem(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
+  constexpr int KROWS = CIN * KH * ((KW + 1) & ~1);
+  constexpr int W_FLOATS = ((KROWS * 64 + 255) / 256) * 256;
+  if (p.plane > PCH * 64 || a.Cin != CIN) return COCLR_EINVAL;
+  if (p.WT > 255 || p.WH > 255 || p.WW > 255 || (1 << p.lTN) > 255) return COCLR_EINVAL;
+  a.mtiles = cdiv(a.Cout, 64);
+  a.planeS = cdiv(p.plane, 64) * 64;
+  a.nchunks = 1;
+  const size_t lds = ((size_t)W_FLOATS + 2 * (size_t)CIN * a.planeS) * sizeof(float);
+  if (lds > 160 * 1024) return COCLR_EINVAL;
+  auto kern = conv_stem_kernel<KH, KW, CIN, PCH>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.ntiles, (unsigned)a.mtiles), dim3(256), lds, stream, a,
+                     p.nboxes);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
 // Weight re-layout:  dst[tap][r][c]  (r < RP rows = reduction channels,
 // c < CP = produced channels), zero padded.
 //   forward : r = cin,  c = cout, src tap = tap_base + tap*tap_step
@@ -486,6 +815,11 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
   } else if (kt == 1 && kh == 7 && kw == 7) {
     conv_pick_box(p, 7, 1, 7, 7);
     *variant = 30;
+    if (p->Cin == 3 && p->dt == 1 && p->dh == 1 && p->dw == 1 && p->plane <= 20 * 64 &&
+        p->WT <= 255 && p->WH <= 255 && p->WW <= 255) {
+      *variant = 31;     // persistent stem kernel: one statistics partial per workgroup
+      if (p->ntiles > kStemGrid) p->ntiles = kStemGrid;
+    }
   } else if (kt == 7 && kh == 1 && kw == 1) {
     conv_pick_box(p, 7, 7, 1, 1);
     *variant = 40;
@@ -566,6 +900,7 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
     case 22: return launch_variant<3, 1, 1, 8, 64, 64, 4>(a, p, stream);
     case 25: return launch_variant<4, 1, 1, 8, 64, 128, 4>(a, p, stream);
     case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);
+    case 31: return launch_stem<7, 7, 3, 20>(a, p, stream);
     case 40: return launch_variant<7, 1, 1, 8, 64, 128, 8>(a, p, stream);
   }
   return COCLR_EINVAL;

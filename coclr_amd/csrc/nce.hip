@@ -257,11 +257,11 @@ positive_mask_kernel(const float* __restrict__ sim, const int64_t* __restrict__ 
 // out[i][:] = in[idx[i]][:]   (rows of `row_elems` floats)
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, float* out,
-                   long row_elems) {
+                   long row_elems, long in_row_stride) {
   const long r = blockIdx.y;
-  const float* src = in + idx[r] * row_elems;
+  const float* src = in + idx[r] * in_row_stride;
   float* dst = out + r * row_elems;
-  if ((row_elems & 3) == 0) {
+  if (((row_elems | in_row_stride) & 3) == 0) {
     const long n4 = row_elems >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
       reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
@@ -437,13 +437,13 @@ extern "C" int coclr_positive_mask(const float* sim, const int64_t* src, const i
 }
 
 extern "C" int coclr_gather_rows(const float* in, const int64_t* idx, float* out, int rows,
-                                 int64_t row_elems, void* stream) {
-  if (rows <= 0 || row_elems <= 0) return COCLR_EINVAL;
+                                 int64_t row_elems, int64_t in_row_stride, void* stream) {
+  if (rows <= 0 || row_elems <= 0 || in_row_stride < row_elems) return COCLR_EINVAL;
   int gx = (int)((row_elems / 4 + 255) / 256);
   if (gx < 1) gx = 1;
   if (gx > 256) gx = 256;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, in, idx,
-                     out, (long)row_elems);
+                     out, (long)row_elems, (long)in_row_stride);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

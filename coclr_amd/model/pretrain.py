@@ -15,6 +15,8 @@ Differences are all below the API:
   * keys cross ranks once: the un-shuffle gather (ref :134) and the enqueue
     gather (ref :85) are the same all_gather_into_tensor over RCCL
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.distributed as dist
@@ -23,6 +25,7 @@ from .. import ops
 from ..backbone.select_backbone import select_backbone
 
 _CHUNK = 32768   # elements per workgroup of the momentum kernel
+_ROUTED_SHUFFLE = os.environ.get("COCLR_SHUFFLE", "routed") != "allgather"
 
 
 def _world():
@@ -363,15 +366,77 @@ class InfoNCE(nn.Module):
             feat = mod(feat)
         return _L2NormFn.apply(feat.view(feat.shape[0], self.dim))
 
+    # -- shuffle-BN exchange: every clip crosses the fabric once ---------------------------
+    def _host_group(self):
+        """gloo side channel for host-resident metadata (the 8*B-entry permutation): lets every
+        rank learn rank 0's permutation on the HOST without a device->host sync."""
+        g = InfoNCE.__dict__.get("_HOST_GROUP")
+        if g is None:
+            g = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+            InfoNCE._HOST_GROUP = g
+        return g
+
+    @torch.no_grad()
+    def _routed_shuffle(self, x2):
+        """Shuffle-BN input exchange (ref :98-124) as a routed all-to-all.
+
+        The reference all-gathers every rank's key clips (201 MB out, 1.4 GB in per rank at
+        world 8) and then keeps B of the B*world it received.  The permutation is known on the
+        host, so each rank sends a clip only to the rank that will encode it: B clips leave and
+        B clips arrive per rank, whatever the world size.
+        Returns (recv buffer (B, C, T, H, W), n_index: row of the buffer holding the i-th clip
+        of this rank's shuffled mini-batch, idx_unshuffle)."""
+        world, rank = _world()
+        B = x2.shape[0]
+        perm = torch.randperm(B * world)                  # same RNG use as the reference (:112)
+        dist.broadcast(perm, src=0, group=self._host_group())
+        p = perm.tolist()
+        # what I send: for destination r, my clips it wants, in the order it wants them
+        send_order, in_splits = [], []
+        for r in range(world):
+            mine = [g % B for g in p[r * B:(r + 1) * B] if g // B == rank]
+            send_order += mine
+            in_splits.append(len(mine))
+        # what I receive: rows grouped by source rank, each group in my wanted order
+        wanted = p[rank * B:(rank + 1) * B]
+        out_splits = [sum(1 for g in wanted if g // B == src) for src in range(world)]
+        offs, acc = [], 0
+        for c in out_splits:
+            offs.append(acc)
+            acc += c
+        seen = [0] * world
+        pos = []
+        for g in wanted:
+            src = g // B
+            pos.append(offs[src] + seen[src])
+            seen[src] += 1
+        dev = x2.device
+        order_t = torch.tensor(send_order, dtype=torch.int64).to(dev, non_blocking=True)
+        sendbuf = torch.empty((B,) + tuple(x2.shape[1:]), dtype=x2.dtype, device=dev)
+        ops.gather_rows(x2, order_t, sendbuf)
+        recvbuf = torch.empty_like(sendbuf)
+        dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=out_splits,
+                               input_split_sizes=in_splits)
+        n_index = torch.tensor(pos, dtype=torch.int64).to(dev, non_blocking=True)
+        idx_unshuffle = torch.argsort(perm).to(dev, non_blocking=True)
+        return recvbuf, n_index, idx_unshuffle
+
     @torch.no_grad()
     def _encode_keys(self, x2):
         """Key path: shuffle -> encoder_k -> normalise -> un-shuffle.
         Returns (k for this rank's samples, keys of the whole global batch in order)."""
         world, rank = _world()
         B = x2.shape[0]
-        idx_this, idx_unshuffle = self._shuffle_indices(B, x2.device)
-        src = concat_all_gather(x2) if world > 1 else x2
-        k_shuf = self._encode(self.encoder_k, src, n_index=idx_this.contiguous())
+        if world > 1 and _ROUTED_SHUFFLE:
+            src, n_index, idx_unshuffle = self._routed_shuffle(x2)
+        elif world > 1:
+            # the reference's own scheme (all-gather, keep B of B*world): COCLR_SHUFFLE=allgather
+            n_index, idx_unshuffle = self._shuffle_indices(B, x2.device)
+            src = concat_all_gather(x2)
+        else:
+            n_index, idx_unshuffle = self._shuffle_indices(B, x2.device)
+            src = x2
+        k_shuf = self._encode(self.encoder_k, src, n_index=n_index.contiguous())
         k_all_shuf = concat_all_gather(k_shuf)
         k_all = torch.empty_like(k_all_shuf)
         ops.gather_rows(k_all_shuf.contiguous(), idx_unshuffle.contiguous(), k_all)

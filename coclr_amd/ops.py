@@ -332,9 +332,16 @@ def positive_mask(sim, src, names, mask, topk):
 
 
 def gather_rows(inp, idx, out):
+    """out[i] = inp[idx[i]]; `inp` rows must be dense but may be strided along dim 0."""
     rows = out.shape[0]
+    row_elems = out.numel() // rows
+    if inp.dim() > 1 and inp[0].numel() == row_elems and inp[0].is_contiguous():
+        in_stride = inp.stride(0) if inp.shape[0] > 1 else row_elems
+    else:
+        raise ValueError("coclr_amd: gather_rows needs dense source rows")
     _lib.check(_lib.load().coclr_gather_rows(_p(inp), _p(idx, torch.int64), _p(out), rows,
-                                             out.numel() // rows, _stream()), "gather_rows")
+                                             row_elems, max(in_stride, row_elems), _stream()),
+               "gather_rows")
 
 
 def relu_fwd(x, y):

@@ -207,9 +207,11 @@ int coclr_queue_advance(int64_t* ptr, int BW, int K, void* stream);
 int coclr_positive_mask(const float* sim, const int64_t* src, const int64_t* names, uint8_t* mask,
                         int B, int K, int topk, void* stream);
 
-/* out[i][:] = in[idx[i]][:] (pretrain.py:124,143). */
+/* out[i][:] = in[idx[i]][:] (pretrain.py:124,143); rows of `row_elems` floats, source rows
+ * `in_row_stride` floats apart (>= row_elems: the second clip of a (B,2,...) pair is a
+ * strided view). */
 int coclr_gather_rows(const float* in, const int64_t* idx, float* out, int rows, int64_t row_elems,
-                      void* stream);
+                      int64_t in_row_stride, void* stream);
 
 /* nn.ReLU of the projection head (pretrain.py:53) and small helpers. */
 int coclr_relu_fwd(const float* x, float* y, int64_t n, void* stream);
