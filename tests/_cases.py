@@ -93,8 +93,11 @@ def fp64_truth_grads(cfg, rec, state_dict, blocks, extra):
     outs = orc.nce_step(sd, kind, cfg["network"], pb, [extra], cfg["dim"], cfg["K"], cfg["m"],
                         cfg["T"], rec["perm"], topk=cfg.get("topk", 5),
                         reverse=cfg.get("reverse", False))
-    loss_fn(kind, *outs[0]).backward()
-    return {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    loss = loss_fn(kind, *outs[0])
+    loss.backward()
+    out = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    out["__loss__"] = loss.detach()
+    return out
 
 
 def compare_step(rec, kind, out, tgt, loss, named_grads, tol=REL_TOL, truth=None,
@@ -115,7 +118,18 @@ def compare_step(rec, kind, out, tgt, loss, named_grads, tol=REL_TOL, truth=None
         assert torch.equal(tgt.cpu(), rec["target"]), "labels"
     else:
         assert torch.equal(tgt.cpu().nonzero(), rec["target"]), "positive mask"
-    check_close(loss, rec["loss"], max(tol, 2e-3), "loss")
+    if truth is not None and "__loss__" in truth:
+        # The loss is ~5e-3 at initialisation (saturated softmax): its RELATIVE error equals the
+        # ABSOLUTE error of the logit gaps, i.e. 14x the logits' max-relative error.  Hold the
+        # product to the float64 loss as tightly as the reference's own fp32 run is (x4), with
+        # the north-star 1e-3 as the floor.
+        l64 = float(truth["__loss__"])
+        e_ref = abs(float(rec["loss"]) - l64) / abs(l64)
+        e_got = abs(float(loss) - l64) / abs(l64)
+        assert e_got <= 4.0 * e_ref + max(tol, 2e-3), \
+            "loss: err vs fp64 %.3e, reference's own fp32 err %.3e" % (e_got, e_ref)
+    else:
+        check_close(loss, rec["loss"], max(tol, 2e-3), "loss")
     if truth is None:
         return
     for k, ref in rec["grads"].items():

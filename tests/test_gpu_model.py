@@ -83,7 +83,9 @@ def _replay(name, with_pg=False):
                                            reverse=cfg.get("reverse", False))
             check_close(out, o_out, 1e-3, "step %d logits vs oracle" % step)
             assert torch.equal(tgt.cpu(), o_tgt), "step %d target" % step
-            check_close(loss, loss_fn(kind, o_out, o_tgt), 2e-3, "step %d loss" % step)
+            # loss ~ 5e-3: relative loss error = absolute logit-gap error (14x the logits'
+            # max-relative error), so 1e-3 on logits bounds it at ~1.4e-2
+            check_close(loss, loss_fn(kind, o_out, o_tgt), 5e-3, "step %d loss" % step)
             assert int(after["queue_ptr"]) == int(sd["queue_ptr"]) == int(rec["queue_ptr"])
             for k, v in sd.items():
                 if ".block" in k:
