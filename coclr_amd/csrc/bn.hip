@@ -163,48 +163,54 @@ bn_act_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__
   sg = block256_sum_d(sg, red);
   sgx = block256_sum_d(sgx, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[2 * c], sg);
-    atomicAdd(&sums[2 * c + 1], sgx);
+    // one partial per (channel, sample group): no atomics, no zero-fill, fixed order
+    sums[((long)c * gridDim.y + blockIdx.y) * 2] = sg;
+    sums[((long)c * gridDim.y + blockIdx.y) * 2 + 1] = sgx;
   }
 }
 
-// Per-channel coefficients for the apply pass and the parameter gradients.
+// Apply pass: folds the per-group partial sums of its channel (fp64), derives
 //   training: dy = A*g + Bc*y + D  with  A = scale, Bc = -scale*invstd*mgx,
-//             D = scale*(mean*invstd*mgx - mg);  eval: dy = scale*g.
-__global__ void bn_bwd_coeff_kernel(const double* __restrict__ sums, const float* __restrict__ scale,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    double count, int C, int training, float* coefA, float* coefB,
-                                    float* coefD, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double sg = sums[2 * c], sgx = sums[2 * c + 1];
-  if (dgamma) dgamma[c] = (float)sgx;
-  if (dbeta) dbeta[c] = (float)sg;
-  const float s = scale[c];
-  if (training) {
-    const float mg = (float)(sg / count), mgx = (float)(sgx / count);
-    coefA[c] = s;
-    coefB[c] = -s * invstd[c] * mgx;
-    coefD[c] = s * (mean[c] * invstd[c] * mgx - mg);
-  } else {
-    coefA[c] = s; coefB[c] = 0.f; coefD[c] = 0.f;
-  }
-}
-
+//             D = scale*(mean*invstd*mgx - mg);  eval: dy = scale*g
+// and the block of sample 0 also emits dgamma / dbeta.
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                         const float* __restrict__ z, const float* __restrict__ scale,
-                        const float* __restrict__ shift, const float* __restrict__ coefA,
-                        const float* __restrict__ coefB, const float* __restrict__ coefD, float* dy,
-                        float* dres, int N, int C, int S, long dz_nstride, long y_nstride,
-                        long dy_nstride, long z_nstride, long dres_nstride, int relu,
-                        int dres_accumulate) {
+                        const float* __restrict__ shift, const float* __restrict__ mean,
+                        const float* __restrict__ invstd, const double* __restrict__ sums,
+                        int groups, double count, int training, float* dgamma, float* dbeta,
+                        float* dy, float* dres, int N, int C, int S, long dz_nstride,
+                        long y_nstride, long dy_nstride, long z_nstride, long dres_nstride,
+                        int relu, int dres_accumulate) {
+  __shared__ double tot[2];
   const int planes = N * C;
   for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
     const int n = pl / C, c = pl - n * C;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double a0 = 0.0, a1 = 0.0;
+      for (int g = threadIdx.x; g < groups; g += 64) {
+        a0 += sums[((long)c * groups + g) * 2];
+        a1 += sums[((long)c * groups + g) * 2 + 1];
+      }
+      a0 = wave_sum_d(a0);
+      a1 = wave_sum_d(a1);
+      if (threadIdx.x == 0) { tot[0] = a0; tot[1] = a1; }
+    }
+    __syncthreads();
+    const double sg = tot[0], sgx = tot[1];
     const float sc = scale[c], sf = shift[c];
-    const float A = coefA[c], B = coefB[c], D = coefD[c];
+    float A = sc, B = 0.f, D = 0.f;
+    if (training) {
+      const float mg = (float)(sg / count), mgx = (float)(sgx / count);
+      B = -sc * invstd[c] * mgx;
+      D = sc * (mean[c] * invstd[c] * mgx - mg);
+    }
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+      if (dgamma) dgamma[c] = (float)sgx;
+      if (dbeta) dbeta[c] = (float)sg;
+    }
     const float* dzp = dz + (long)n * dz_nstride + (long)c * S;
     const float* yp = y + (long)n * y_nstride + (long)c * S;
     const float* zp = z ? z + (long)n * z_nstride + (long)c * S : nullptr;
@@ -308,22 +314,26 @@ extern "C" int coclr_bn_act_apply(const float* y, const float* scale, const floa
   return 0;
 }
 
+extern "C" int coclr_bn_backward_workspace(int N, int C, int64_t* doubles) {
+  if (N <= 0 || C <= 0) return COCLR_EINVAL;
+  *doubles = (int64_t)2 * C * N;
+  return 0;
+}
+
 extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const float* z,
                                      const float* scale, const float* shift, const float* mean,
-                                     const float* invstd, double* sums_ws, float* coef_ws, float* dy,
-                                     float* dres, float* dgamma, float* dbeta, int N, int C,
-                                     int64_t S, int64_t dz_nstride, int64_t y_nstride,
-                                     int64_t dy_nstride, int64_t z_nstride, int64_t dres_nstride,
-                                     int relu, int training, int dres_accumulate, void* stream_) {
+                                     const float* invstd, double* sums_ws, float* dy, float* dres,
+                                     float* dgamma, float* dbeta, int N, int C, int64_t S,
+                                     int64_t dz_nstride, int64_t y_nstride, int64_t dy_nstride,
+                                     int64_t z_nstride, int64_t dres_nstride, int relu,
+                                     int training, int dres_accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N <= 0 || C <= 0 || S <= 0) return COCLR_EINVAL;
   const bool vec = (S % 4 == 0) && (dz_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
                    (dy_nstride % 4 == 0) && (!z || z_nstride % 4 == 0) &&
                    (!dres || dres_nstride % 4 == 0);
-  COCLR_RETURN_IF(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, stream));
-  int gy = N;
-  // more split for tiny batches of huge planes is not needed: planes are big then
-  dim3 rgrid(C, gy);
+  // pass 1: per (channel, sample) partial sums of g and g*xhat
+  dim3 rgrid(C, N);
   if (vec)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, stream, dz, y, z, scale,
                        shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride,
@@ -333,24 +343,19 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
                        scale, shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride,
                        (long)y_nstride, (long)z_nstride, relu);
   COCLR_LAUNCH_CHECK();
-  float* coefA = coef_ws;
-  float* coefB = coef_ws + C;
-  float* coefD = coef_ws + 2 * C;
-  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums_ws, scale,
-                     mean, invstd, (double)N * (double)S, C, training, coefA, coefB, coefD, dgamma,
-                     dbeta);
-  COCLR_LAUNCH_CHECK();
+  // pass 2: fold the partials, coefficients, dy (+ dres), dgamma / dbeta
+  const double count = (double)N * (double)S;
   dim3 grid = plane_grid(N * C, (int)S);
   if (vec)
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, grid, dim3(256), 0, stream, dz, y, z, scale,
-                       shift, coefA, coefB, coefD, dy, dres, N, C, (int)S, (long)dz_nstride,
-                       (long)y_nstride, (long)dy_nstride, (long)z_nstride, (long)dres_nstride, relu,
-                       dres_accumulate);
+                       shift, mean, invstd, sums_ws, N, count, training, dgamma, dbeta, dy, dres, N,
+                       C, (int)S, (long)dz_nstride, (long)y_nstride, (long)dy_nstride,
+                       (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
   else
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, grid, dim3(256), 0, stream, dz, y, z, scale,
-                       shift, coefA, coefB, coefD, dy, dres, N, C, (int)S, (long)dz_nstride,
-                       (long)y_nstride, (long)dy_nstride, (long)z_nstride, (long)dres_nstride, relu,
-                       dres_accumulate);
+                       shift, mean, invstd, sums_ws, N, count, training, dgamma, dbeta, dy, dres, N,
+                       C, (int)S, (long)dz_nstride, (long)y_nstride, (long)dy_nstride,
+                       (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

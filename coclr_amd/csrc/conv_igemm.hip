@@ -734,22 +734,34 @@ inline double cover(int cout, int bm) { return (double)cout / ((double)cdiv(cout
 struct Choice { int bm, lbn; };
 
 // Decide (BM, BN) for a stencil class given which variants exist.
+//
+// Cost model: the matrix pipes are the bound, so a launch takes (workgroups that land on the
+// busiest CU) x (MFMAs per workgroup).  When the whole grid is co-resident (<= 6 workgroups
+// per CU) the busiest CU holds ceil(nWG / 256) of them -- 640 tiles of 64x128 cost 3 rounds
+// although the average is 2.5 -- so the tile that divides the layer evenly wins even if it is
+// smaller; 64x64 tiles pay ~10 % for twice the operand traffic per MFMA.
 Choice choose_tile(const ConvPlan& base, int kt, int kh, int kw, bool has128x128, bool has64x64,
                    int max_plane_128, int max_plane_64) {
-  Choice c{64, 7};
-  ConvPlan p = base;
-  conv_pick_box(&p, 7, kt, kh, kw);
-  const bool fits128 = p.plane <= max_plane_128;
-  long blocks64 = (long)p.ntiles * cdiv(base.Cout, 64);
-  if (has128x128 && fits128 && cover(base.Cout, 128) >= cover(base.Cout, 64) - 1e-9 &&
-      (long)p.ntiles * cdiv(base.Cout, 128) >= 384)
-    c.bm = 128;
-  if (!fits128 || (has64x64 && blocks64 < 384)) {
-    ConvPlan p6 = base;
-    conv_pick_box(&p6, 6, kt, kh, kw);
-    if (has64x64 && p6.plane <= max_plane_64) { c.bm = 64; c.lbn = 6; }
+  struct Cand { int bm, lbn, max_plane; double eff; bool have; };
+  const Cand cands[3] = {{128, 7, max_plane_128, 1.00, has128x128},
+                         {64, 7, max_plane_128, 1.00, true},
+                         {64, 6, max_plane_64, 0.90, has64x64}};
+  Choice best{64, 7};
+  double best_cost = -1.0;
+  for (const Cand& cd : cands) {
+    if (!cd.have) continue;
+    ConvPlan p = base;
+    conv_pick_box(&p, cd.lbn, kt, kh, kw);
+    if (p.plane > cd.max_plane) continue;
+    const double nwg = (double)p.ntiles * cdiv(base.Cout, cd.bm);
+    const double per_cu = nwg <= 256.0 * 6 ? (double)cdiv((long)nwg, 256) : nwg / 256.0;
+    const double cost = per_cu * (cd.bm / 64) * ((1 << cd.lbn) / 64) / cd.eff;
+    if (best_cost < 0 || cost < best_cost - 1e-9) {   // ties keep the larger tile (listed first)
+      best_cost = cost;
+      best.bm = cd.bm; best.lbn = cd.lbn;
+    }
   }
-  return c;
+  return best;
 }
 
 }  // namespace

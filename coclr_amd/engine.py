@@ -225,15 +225,13 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
             dz = run.grad_of(out)
             dy = torch.empty_like(y)
             dgb = run.empty(2, Cout)
-            sums = run.empty(2 * Cout, dtype=torch.float64)
-            coef = run.empty(3 * Cout)
+            sums = run.empty(ops.bn_backward_workspace(N, Cout), dtype=torch.float64)
             dres = None
             dres_acc = False
             if residual is not None and run.needs_grad(residual):
                 dres, dres_acc = run.grad_target(residual)
             ops.bn_act_backward(dz, y, zv if residual is not None else None, scale, shift, mean,
-                                invstd, sums, coef, dy, dres, dgb[0], dgb[1], relu, training,
-                                dres_acc)
+                                invstd, sums, dy, dres, dgb[0], dgb[1], relu, training, dres_acc)
             if bn.weight.requires_grad:
                 run.add_param_grad(bn.weight, dgb[0])
             if bn.bias.requires_grad:
@@ -325,11 +323,10 @@ def pointwise_group(run, x, units):
             dy = torch.empty_like(y)
             for (conv, bn, _), out, (c0, C_, mean, invstd, scale, shift) in zip(units, outs, saved):
                 dgb = run.empty(2, C_)
-                sums = run.empty(2 * C_, dtype=torch.float64)
-                coef = run.empty(3 * C_)
+                sums = run.empty(ops.bn_backward_workspace(N, C_), dtype=torch.float64)
                 ops.bn_act_backward(run.grad_of(out), y[:, c0:c0 + C_], None, scale, shift, mean,
-                                    invstd, sums, coef, dy[:, c0:c0 + C_], None, dgb[0], dgb[1],
-                                    True, training)
+                                    invstd, sums, dy[:, c0:c0 + C_], None, dgb[0], dgb[1], True,
+                                    training)
                 if bn.weight.requires_grad:
                     run.add_param_grad(bn.weight, dgb[0])
                 if bn.bias.requires_grad:

@@ -216,13 +216,20 @@ def bn_act_apply(y, scale, shift, residual, z, relu):
         "bn_act_apply")
 
 
-def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, coef_ws, dy, dres, dgamma,
-                    dbeta, relu, training, dres_accumulate=False):
+def bn_backward_workspace(N, C_):
+    """float64 elements of the partial-sum workspace of bn_act_backward."""
+    return 2 * C_ * N
+
+
+def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dgamma, dbeta, relu,
+                    training, dres_accumulate=False):
     N, C_, T, H, W = y.shape
     S = T * H * W
+    if sums_ws.numel() < 2 * C_ * N:
+        raise ValueError("coclr_amd: bn_act_backward workspace too small")
     _lib.check(_lib.load().coclr_bn_act_backward(
         _p(dz), _p(y), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd),
-        _p(sums_ws, torch.float64), _p(coef_ws), _p(dy), _p(dres), _p(dgamma), _p(dbeta), N, C_, S,
+        _p(sums_ws, torch.float64), _p(dy), _p(dres), _p(dgamma), _p(dbeta), N, C_, S,
         _chk5(dz, "dz"), _chk5(y, "y"), _chk5(dy, "dy"), _chk5(z, "z") if z is not None else 0,
         _chk5(dres, "dres") if dres is not None else 0, int(relu), int(training),
         int(dres_accumulate), _stream()), "bn_act_backward")

@@ -127,15 +127,16 @@ int coclr_bn_act_apply(const float* y, const float* scale, const float* shift,
 
 /* Backward of the above (aten::threshold_backward + native_batch_norm_backward):
  * dy, dgamma, dbeta and, for residual units, dres (+)= masked dz.
- * z may be NULL (ReLU mask is then recomputed from y).  sums_ws: 2*C doubles,
- * coef_ws: 3*C floats. */
+ * z may be NULL (ReLU mask is then recomputed from y).  sums_ws: fp64 partial sums, one
+ * pair per (channel, sample) -- coclr_bn_backward_workspace doubles; no zero-fill needed,
+ * no atomics (run-to-run deterministic). */
+int coclr_bn_backward_workspace(int N, int C, int64_t* doubles);
 int coclr_bn_act_backward(const float* dz, const float* y, const float* z, const float* scale,
                           const float* shift, const float* mean, const float* invstd,
-                          double* sums_ws, float* coef_ws, float* dy, float* dres, float* dgamma,
-                          float* dbeta, int N, int C, int64_t S, int64_t dz_nstride,
-                          int64_t y_nstride, int64_t dy_nstride, int64_t z_nstride,
-                          int64_t dres_nstride, int relu, int training, int dres_accumulate,
-                          void* stream);
+                          double* sums_ws, float* dy, float* dres, float* dgamma, float* dbeta,
+                          int N, int C, int64_t S, int64_t dz_nstride, int64_t y_nstride,
+                          int64_t dy_nstride, int64_t z_nstride, int64_t dres_nstride, int relu,
+                          int training, int dres_accumulate, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Pooling (backbone/s3dg.py:105,151,162,173,190; resnet_2d3d.py:141;        */

@@ -151,7 +151,11 @@ def bn_act_apply(y, scale, shift, residual, z, relu):
     z.copy_(torch.relu(v) if relu else v)
 
 
-def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, coef_ws, dy, dres, dgamma,
+def bn_backward_workspace(N, C_):
+    return 2 * C_ * N
+
+
+def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dgamma,
                     dbeta, relu, training, dres_accumulate=False):
     g = dz
     if relu:

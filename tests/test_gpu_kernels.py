@@ -235,9 +235,9 @@ def test_batchnorm_train_fwd_bwd(shape, relu, res):
     dgb = torch.empty(2, Cc, device="cuda")
     dres = torch.full(shape, 1.0, device="cuda") if res else None
     ops.bn_act_backward(dzw[:, 3:3 + Cc], yd, zd if res else None, small[2], small[3], small[0],
-                        small[1], torch.empty(2 * Cc, dtype=torch.float64, device="cuda"),
-                        torch.empty(3 * Cc, device="cuda"), dy, dres, dgb[0], dgb[1], relu, True,
-                        dres_accumulate=res)
+                        small[1], torch.full((ops.bn_backward_workspace(N, Cc),), float("nan"),
+                                             dtype=torch.float64, device="cuda"),
+                        dy, dres, dgb[0], dgb[1], relu, True, dres_accumulate=res)
     close(dy, y.grad, rtol=5e-4, what="bn dy")
     close(dgb[0], gamma.grad, rtol=5e-4, what="dgamma")
     close(dgb[1], beta.grad, rtol=5e-4, what="dbeta")
