@@ -82,7 +82,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // exact floor(e / d) for 0 <= e < 2^20 given inv = 1.0f / d
 __device__ __forceinline__ int fdiv(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
 
-template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH>
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvArgs a) {
   constexpr int TAPS = KT * KH * KW;
@@ -164,6 +164,21 @@ conv_igemm_kernel(const ConvArgs a) {
   }
   // weights: lane's row inside a piece and column
   const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
+  // XV4 (pointwise, box = a run of BN contiguous positions, everything 16-byte aligned): the
+  // window IS the box, staged with 16-byte DMA -- one piece = 256/BN channel rows
+  unsigned xv4off = OOB;
+  int xv4c = 0;
+  if (XV4) {
+    const int e = (lane % (BN / 4)) * 4;
+    xv4c = lane / (BN / 4);
+    const int wn_ = e >> a.lTW;                 // plane1 == 1 << lTW here
+    const int iw = ow0 + (e & ((1 << a.lTW) - 1));
+    const int n = n0 + wn_;
+    if (n < a.N && iw < a.Wi) {
+      const long ns = gather ? (long)a.n_index[n] : (long)wn_;
+      xv4off = (unsigned)((ns * a.x_nstride + iw + (long)xv4c * a.x_cstride) * 4);
+    }
+  }
 
   // ---- per-lane MFMA operand bases ----------------------------------------
   int lanebase[NF];
@@ -198,6 +213,15 @@ conv_igemm_kernel(const ConvArgs a) {
     }
     // input window: channels wave, wave+4, ...
     float* xs = sbase + W_FLOATS;
+    if (XV4) {
+      constexpr int CPP = 256 / BN;              // channel rows per 1 KiB piece
+      for (int p = wave; p < CC / CPP; p += 4) {
+        const int cin = cin0 + p * CPP;
+        const unsigned vo = cin + xv4c < a.Cin ? xv4off : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + p * 256), 16, vo,
+                                                 (unsigned)cin * (unsigned)a.x_cstride * 4u, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int ci = 0; ci < CC / 4; ++ci) {
       const int c = ci * 4 + wave;
@@ -703,7 +727,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 inline int pad_to(int v, int m) { return ((v + m - 1) / m) * m; }
 
-template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH>
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false>
 int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   constexpr int TAPS = KT * KH * KW;
   if (p.plane > PCH * 64) return COCLR_EINVAL;
@@ -715,7 +739,7 @@ int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PCH>;
+  auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PCH, XV4>;
   static bool attr_done = false;
   if (!attr_done) {
     COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -739,7 +763,8 @@ struct Choice { int bm, lbn; };
 // busiest CU) x (MFMAs per workgroup).  When the whole grid is co-resident (<= 6 workgroups
 // per CU) the busiest CU holds ceil(nWG / 256) of them -- 640 tiles of 64x128 cost 3 rounds
 // although the average is 2.5 -- so the tile that divides the layer evenly wins even if it is
-// smaller; 64x64 tiles pay ~10 % for twice the operand traffic per MFMA.
+// smaller; 64x64 tiles pay ~10 % for twice the operand traffic per MFMA, and a grid that
+// leaves one workgroup per CU pays ~20 % (measured on the 8x8x8 stage, profiles/r01_layers_*).
 Choice choose_tile(const ConvPlan& base, int kt, int kh, int kw, bool has128x128, bool has64x64,
                    int max_plane_128, int max_plane_64) {
   struct Cand { int bm, lbn, max_plane; double eff; bool have; };
@@ -755,7 +780,9 @@ Choice choose_tile(const ConvPlan& base, int kt, int kh, int kw, bool has128x128
     if (p.plane > cd.max_plane) continue;
     const double nwg = (double)p.ntiles * cdiv(base.Cout, cd.bm);
     const double per_cu = nwg <= 256.0 * 6 ? (double)cdiv((long)nwg, 256) : nwg / 256.0;
-    const double cost = per_cu * (cd.bm / 64) * ((1 << cd.lbn) / 64) / cd.eff;
+    // a lone workgroup per CU (one wave per SIMD) cannot hide its own staging / epilogue
+    const double occ_eff = per_cu < 1.5 ? 0.80 : (per_cu < 2.5 ? 0.95 : 1.0);
+    const double cost = per_cu * (cd.bm / 64) * ((1 << cd.lbn) / 64) / (cd.eff * occ_eff);
     if (best_cost < 0 || cost < best_cost - 1e-9) {   // ties keep the larger tile (listed first)
       best_cost = cost;
       best.bm = cd.bm; best.lbn = cd.lbn;
@@ -898,10 +925,19 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
   if (((double)(1 << p.lTN) * (double)a.y_nstride + (double)(a.Cout + 128) * a.y_cstride) * 4.0 >= lim)
     return COCLR_EINVAL;
   if ((double)d->kt * d->kh * d->kw * a.CinP * a.CoutP * 4.0 >= lim) return COCLR_EINVAL;
+  // pointwise with the box a contiguous, 16-byte aligned run of exactly BN positions:
+  // 16-byte LDS-DMA for the input too
+  const int bn_v = variant == 2 ? 64 : 128;
+  const bool xv4 = variant <= 2 && p.Hi == 1 && p.Ti == 1 && p.lTH == 0 && p.lTT == 0 && p.lTW >= 2 &&
+                   p.plane == bn_v && (p.Wi % 4) == 0 && (a.x_cstride % 4) == 0 &&
+                   (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0;
   switch (variant) {
-    case 0:  return launch_variant<1, 1, 1, 32, 128, 128, 2>(a, p, stream);
-    case 1:  return launch_variant<1, 1, 1, 32, 64, 128, 2>(a, p, stream);
-    case 2:  return launch_variant<1, 1, 1, 32, 64, 64, 1>(a, p, stream);
+    case 0:  return xv4 ? launch_variant<1, 1, 1, 32, 128, 128, 2, true>(a, p, stream)
+                        : launch_variant<1, 1, 1, 32, 128, 128, 2>(a, p, stream);
+    case 1:  return xv4 ? launch_variant<1, 1, 1, 32, 64, 128, 2, true>(a, p, stream)
+                        : launch_variant<1, 1, 1, 32, 64, 128, 2>(a, p, stream);
+    case 2:  return xv4 ? launch_variant<1, 1, 1, 32, 64, 64, 1, true>(a, p, stream)
+                        : launch_variant<1, 1, 1, 32, 64, 64, 1>(a, p, stream);
     case 3:  return launch_variant<1, 1, 1, 16, 64, 64, 4>(a, p, stream);
     case 10: return launch_variant<1, 3, 3, 4, 128, 128, 4>(a, p, stream);
     case 11: return launch_variant<1, 3, 3, 8, 64, 128, 4>(a, p, stream);

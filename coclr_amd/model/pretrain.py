@@ -26,6 +26,7 @@ from ..backbone.select_backbone import select_backbone
 
 _CHUNK = 32768   # elements per workgroup of the momentum kernel
 _ROUTED_SHUFFLE = os.environ.get("COCLR_SHUFFLE", "routed") != "allgather"
+_OVERLAP_KEYS = os.environ.get("COCLR_OVERLAP_KEYS", "1") != "0"
 
 
 def _world():
@@ -358,6 +359,27 @@ class InfoNCE(nn.Module):
         ops.gather_rows(x_gather, idx_this, out)
         return out
 
+    # -- key path on its own HIP stream --------------------------------------------------
+    def _key_stream(self, x):
+        """The key encoder (no gradient) is independent of the query encoder's forward: run it
+        on a second stream so its launches fill the CUs the query encoder's small late-stage
+        kernels leave idle (and vice versa).  Ordering: the side stream first waits for
+        everything already queued (the previous optimiser step writes the query weights the
+        momentum update reads); the caller joins before the logits."""
+        if not (_OVERLAP_KEYS and x.is_cuda):
+            return None
+        st = self.__dict__.get("_side_stream")
+        if st is None or st.device != x.device:
+            st = torch.cuda.Stream(device=x.device)
+            self.__dict__["_side_stream"] = st
+        st.wait_stream(torch.cuda.current_stream(x.device))
+        return st
+
+    @staticmethod
+    def _join(st):
+        if st is not None:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+
     # -- encoders --------------------------------------------------------------------
     def _encode(self, encoder, x, n_index=None):
         """encoder(x) -> L2-normalised (B, dim); x may be a strided clip view."""
@@ -453,13 +475,15 @@ class InfoNCE(nn.Module):
         x1, x2 = self._split_pair(block)
         B = x1.shape[0]
 
+        side = self._key_stream(x1)
         q = self._encode(self.encoder_q, x1)
         in_train_mode = q.requires_grad
 
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.stream(side):
             if in_train_mode:
                 self._momentum_update_key_encoder()
             k, k_all = self._encode_keys(x2)
+        self._join(side)
 
         logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
         labels = torch.zeros(B, dtype=torch.long, device=logits.device)
@@ -491,13 +515,15 @@ class UberNCE(InfoNCE):
         x1, x2 = self._split_pair(block)
         B = x1.shape[0]
 
+        side = self._key_stream(x1)
         q = self._encode(self.encoder_q, x1)
         in_train_mode = q.requires_grad
 
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.stream(side):
             if in_train_mode:
                 self._momentum_update_key_encoder()
             k, k_all = self._encode_keys(x2)
+        self._join(side)
 
         logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
 
@@ -558,16 +584,18 @@ class CoCLR(InfoNCE):
             x2, f2 = f2, x2
         B = x1.shape[0]
 
+        side = self._key_stream(x1)
         q = self._encode(self.encoder_q, x1)
         in_train_mode = q.requires_grad
 
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.stream(side):
             if in_train_mode:
                 self._momentum_update_key_encoder()
             k, k_all = self._encode_keys(x2)
             # second view: frozen sampler (eval-mode BN in the reference's training loop),
             # not shuffled
             kf = self._encode(self.sampler, f2)
+        self._join(side)
 
         logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
 
