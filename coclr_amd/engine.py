@@ -16,9 +16,15 @@ What that buys on MI355X:
     kernel) instead of separate add kernels
   * the launch sequence is static per input shape (hipGraph-capturable)
 """
+import os
+
 import torch
 
 from . import ops
+
+
+WGRAD_STREAM = os.environ.get("COCLR_WGRAD_STREAM", "1") != "0"
+_SIDE = {}
 
 
 class Val:
@@ -94,7 +100,30 @@ class Run:
         self.grads[id(out.base)] = dout.contiguous()
         while self.tape:
             self.tape.pop()()
+        self.join_side()
         return self.grads
+
+    # Weight gradients feed nothing inside the backward pass (only the optimiser), so they
+    # run on a second stream: the dgrad -> BN-backward chain of the next unit proceeds on
+    # the main stream while the wgrad of this unit fills whatever CUs it leaves idle.
+    def side_stream(self, *inputs):
+        """Stream for work that depends on `inputs` (tensors produced on the main stream) but
+        that nothing later on the main stream waits for until `join_side`."""
+        if not (WGRAD_STREAM and self.device.type == "cuda"):
+            return None
+        st = _SIDE.get(self.device)
+        if st is None:
+            st = _SIDE[self.device] = torch.cuda.Stream(device=self.device)
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        for t in inputs:
+            t.record_stream(st)      # the allocator must not recycle it under the side kernels
+        self._side_used = True
+        return st
+
+    def join_side(self):
+        if getattr(self, "_side_used", False):
+            torch.cuda.current_stream(self.device).wait_stream(_SIDE[self.device])
+            self._side_used = False
 
     # -- weight packing ------------------------------------------------------------
     def pack(self, w, transpose, kt_slice=None, taps=None, tap_base=0, tap_step=1):
@@ -237,12 +266,13 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
             if bn.bias.requires_grad:
                 run.add_param_grad(bn.bias, dgb[1])
             if w.requires_grad:
-                dw = torch.empty_like(w)
-                kk = w.shape[2] * w.shape[3] * w.shape[4]
-                for t, g in enumerate(geoms):
-                    ws = run.empty(g.wgrad_workspace())
-                    ops.conv_wgrad(g, xv, dy, dw, ws, Cin * kk, kk,
-                                   t * k[1] * k[2] if sliced else 0)
+                with torch.cuda.stream(run.side_stream(dy)):
+                    dw = torch.empty_like(w)
+                    kk = w.shape[2] * w.shape[3] * w.shape[4]
+                    for t, g in enumerate(geoms):
+                        ws = run.empty(g.wgrad_workspace())
+                        ops.conv_wgrad(g, xv, dy, dw, ws, Cin * kk, kk,
+                                       t * k[1] * k[2] if sliced else 0)
                 run.add_param_grad(w, dw)
             if x_needs:
                 if sliced:
@@ -332,9 +362,10 @@ def pointwise_group(run, x, units):
                 if bn.bias.requires_grad:
                     run.add_param_grad(bn.bias, dgb[1])
             if any(w.requires_grad for w in weights):
-                dw = run.empty(Ccat, Cin, 1, 1, 1)
-                ws = run.empty(geom.wgrad_workspace())
-                ops.conv_wgrad(geom, xv, dy, dw, ws, Cin, 1, 0)
+                with torch.cuda.stream(run.side_stream(dy)):
+                    dw = run.empty(Ccat, Cin, 1, 1, 1)
+                    ws = run.empty(geom.wgrad_workspace())
+                    ops.conv_wgrad(geom, xv, dy, dw, ws, Cin, 1, 0)
                 c0 = 0
                 for w in weights:
                     if w.requires_grad:
