@@ -153,15 +153,19 @@ class SepInception(_Emitter):
         heads = engine.pointwise_group(run, x, [(b0.conv, b0.bn, None if self.gating else dst[0]),
                                                 (b1a.conv, b1a.bn, None), (b2a.conv, b2a.bn, None)])
         tails = (None, self.branch1[1], self.branch2[1])
-        for i in range(4):
-            if i == 3:
-                y = self.branch3._emit(run, x, out=None if self.gating else dst[3])
-            elif tails[i] is not None:
-                y = tails[i]._emit(run, heads[i], out=None if self.gating else dst[i])
-            else:
-                y = heads[0]
-            if self.gating:
-                getattr(self, "gating_b%d" % i)._emit(run, y, out=dst[i])
+        if self.gating:
+            getattr(self, "gating_b0")._emit(run, heads[0], out=dst[0])
+        # the separable tails of branch 1 / 2 and the pool branch are independent of each other:
+        # one lane (HIP stream) each, joined before the block output is consumed
+        for i in (1, 2, 3):
+            with run.lane(i):
+                if i == 3:
+                    y = self.branch3._emit(run, x, out=None if self.gating else dst[3])
+                else:
+                    y = tails[i]._emit(run, heads[i], out=None if self.gating else dst[i])
+                if self.gating:
+                    getattr(self, "gating_b%d" % i)._emit(run, y, out=dst[i])
+        run.join_lanes()
         return engine.Val(block)
 
 

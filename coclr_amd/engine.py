@@ -24,7 +24,37 @@ from . import ops
 
 
 WGRAD_STREAM = os.environ.get("COCLR_WGRAD_STREAM", "1") != "0"
+# Inception branches on their own streams: correct (GPU tier passes with it on) but SLOWER on
+# MI355X -- 47.3 vs 43.3 ms/step: ~160 fork/join points per step cost more in cross-queue
+# event latency than the overlap of the small branch kernels wins.  Off unless asked for.
+LANES = os.environ.get("COCLR_LANES", "0") == "1"
 _SIDE = {}
+_LANES = {}
+
+
+class _Lane:
+    def __init__(self, run, idx):
+        self.run, self.idx, self.ctx = run, idx, None
+
+    def __enter__(self):
+        run = self.run
+        if run.cur_lane is not None:
+            raise RuntimeError("coclr_amd: lanes do not nest")
+        if LANES and run.device.type == "cuda":
+            st, parent = run._lane_stream(self.idx)
+            st.wait_stream(parent)
+            run._parent = parent
+            run._open.append(st)
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+        run.cur_lane = self.idx
+        return self
+
+    def __exit__(self, *exc):
+        self.run.cur_lane = None
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 class Val:
@@ -60,7 +90,10 @@ class Run:
         self.device = device
         self.save = save
         self.need_input_grad = need_input_grad
-        self.tape = []
+        self.tape = []         # (closure, lane) in emission order
+        self.cur_lane = None
+        self._parent = None
+        self._open = []
         self.grads = {}        # id(base tensor) -> grad tensor
         self.param_grads = {}  # id(param) -> grad tensor
         self.no_grad_bases = set()
@@ -94,12 +127,60 @@ class Run:
         old = self.param_grads.get(id(p))
         self.param_grads[id(p)] = g if old is None else old.add_(g)
 
+    # -- lanes: independent sub-graphs (inception branches) on their own streams ------
+    def record(self, fn):
+        self.tape.append((fn, self.cur_lane))
+
+    def _lane_stream(self, lane):
+        parent = torch.cuda.current_stream(self.device) if self.cur_lane is None else self._parent
+        key = (self.device, parent.cuda_stream, lane)
+        st = _LANES.get(key)
+        if st is None:
+            st = _LANES[key] = torch.cuda.Stream(device=self.device)
+        return st, parent
+
+    def lane(self, idx):
+        """Context: kernels emitted inside run on lane stream `idx`, ordered after everything
+        queued on the parent stream so far.  The caller closes the region with join_lanes()."""
+        return _Lane(self, idx)
+
+    def join_lanes(self):
+        if self._open:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self._open:
+                cur.wait_stream(st)
+            self._open = []
+
     # -- backward ----------------------------------------------------------------
     def backward(self, dout):
         out = self.out
         self.grads[id(out.base)] = dout.contiguous()
+        # closures run in reverse emission order; closures of different lanes between two
+        # main-stream closures are independent of each other, so each lane replays on its own
+        # stream (entered after the main stream's work so far) and the next main-stream
+        # closure joins them
+        started = {}
         while self.tape:
-            self.tape.pop()()
+            fn, lane = self.tape.pop()
+            if lane is None or not (LANES and self.device.type == "cuda"):
+                if started:
+                    cur = torch.cuda.current_stream(self.device)
+                    for st in started.values():
+                        cur.wait_stream(st)
+                    started = {}
+                fn()
+            else:
+                st = started.get(lane)
+                if st is None:
+                    st, parent = self._lane_stream(lane)
+                    st.wait_stream(parent)
+                    started[lane] = st
+                with torch.cuda.stream(st):
+                    fn()
+        if started:
+            cur = torch.cuda.current_stream(self.device)
+            for st in started.values():
+                cur.wait_stream(st)
         self.join_side()
         return self.grads
 
@@ -287,7 +368,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                 else:
                     ops.conv_fwd(geoms[0].dgrad(), dy, run.pack(w, True), dx, accumulate=acc)
 
-        run.tape.append(backward)
+        run.record(backward)
     elif y is not None:
         del y
     return out
@@ -375,7 +456,7 @@ def pointwise_group(run, x, units):
                 dx, acc = run.grad_target(x)
                 ops.conv_fwd(geom.dgrad(), dy, run.pack_concat(weights, True), dx, accumulate=acc)
 
-        run.tape.append(backward)
+        run.record(backward)
     return outs
 
 
@@ -396,7 +477,7 @@ def max_pool(run, x, kernel, stride, padding):
         def backward():
             dx, acc = run.grad_target(x)
             ops.maxpool_bwd(g, run.grad_of(out), idx, dx, accumulate=acc)
-        run.tape.append(backward)
+        run.record(backward)
     elif run.save:
         run.no_grad_bases.add(id(y))
     return out
@@ -435,7 +516,7 @@ def self_gating(run, x, fc, out=None):
                     g.add_(dx)
                 else:
                     g.copy_(dx)
-        run.tape.append(backward)
+        run.record(backward)
     return out
 
 
