@@ -435,6 +435,196 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Stem weight gradient: (1,KH,KW) stencil over CIN = 3 input channels (s3dg.py:145 conv1 and
+// the slices of resnet_2d3d.py:138).  J = CIN*KH*KW = 147 columns would half-fill a second
+// 128-column tile of the (ci,tap)-lane kernel and its window reads collide in LDS.  Here:
+//   * every matrix wave owns the WHOLE 64 x 160 (= J padded to 5 x 32) tile of dW and a
+//     quarter of each box's positions (split-K inside the workgroup: the four partial tiles
+//     go out as four split slices, folded by wgrad_reduce_kernel with the rest);
+//   * per MFMA step: 2 dY operands + 5 window operands -> 10 MFMAs;
+//   * the window sits in LDS with a row pitch == 7 (mod 32), so the 32 (kh,kw) offsets of a
+//     column block fall into distinct banks;
+//   * waves 4-7 are loaders (LDS-DMA, two stages, one barrier per 128-position box).
+template <int KH, int KW, int CIN, int PCH>
+__global__ void __launch_bounds__(512)
+conv_wgrad_stem_kernel(const Wgrad2Args a) {
+  constexpr int TAPS = KH * KW, J = CIN * TAPS, NJB = (J + 31) / 32;
+  constexpr int BP = 128;                // positions per box
+  constexpr int BMt = 64;
+  constexpr int LDY = BP + 1;
+  constexpr int STEPS = BP / 8;          // per matrix wave: BP/4 positions, 2 per step
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeP = a.planeP;
+  const int stage_floats = BMt * LDY + CIN * planeP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int co0 = blockIdx.z * BMt;
+  const int nbox = (a.ntiles - split + a.S - 1) / a.S;
+  const int lW = a.lTW, lWH = a.lTW + a.lTH, lWHT = a.lTW + a.lTH + a.lTT;
+
+  if (wave >= 4) {
+    // =============================== loader waves ===============================
+    const int lw = wave - 4;
+    constexpr int PW = (PCH + 3) / 4;    // window pieces lw, lw+4, ... of every channel
+    int wn_[PW], wt_[PW], wh_[PW], ww_[PW];
+    {
+      const int hw = a.WH * a.WW;
+#pragma unroll
+      for (int jj = 0; jj < PW; ++jj) {
+        const int e = (lw + 4 * jj) * 64 + lane;
+        const int q0 = w2_fdiv(e, a.inv_plane1);
+        int q = e - q0 * a.plane1;
+        const int t = w2_fdiv(q, a.inv_hw); q -= t * hw;
+        const int h = w2_fdiv(q, a.inv_ww);
+        wn_[jj] = q0; wt_[jj] = t; wh_[jj] = h; ww_[jj] = q - h * a.WW;
+      }
+    }
+    for (int b = 0; b < nbox; ++b) {
+      const int tile = split + b * a.S;
+      int r = tile;
+      const int bw_ = r % a.nbw; r /= a.nbw;
+      const int bh_ = r % a.nbh; r /= a.nbh;
+      const int bt_ = r % a.nbt; r /= a.nbt;
+      const int n0 = r << a.lTN;
+      const int ow0 = bw_ << lW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;
+      float* dYs = smem + (b & 1) * stage_floats;
+      float* Xs = dYs + BMt * LDY;
+      // ---- dY[64][128]: rows lw, lw+4, ...; two 64-position pieces per row --------------
+      {
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.dy + (long)n0 * a.dy_nstride), 0, 0x80000000u, 0x00020000);
+        unsigned voff[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int p = h * 64 + lane;
+          const int tw = p & ((1 << lW) - 1);
+          const int th = (p >> lW) & ((1 << a.lTH) - 1);
+          const int tt = (p >> lWH) & ((1 << a.lTT) - 1);
+          const int tn = p >> lWHT;
+          const int n = n0 + tn, ot = ot0 + tt, oh = oh0 + th, ow = ow0 + tw;
+          const bool ok = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
+          voff[h] = ok ? (unsigned)(((long)tn * a.dy_nstride + ((long)ot * a.Ho + oh) * a.Wo + ow) * 4)
+                       : W2_OOB;
+        }
+        for (int row = lw; row < BMt; row += 4) {
+          const int co = co0 + row;
+          const unsigned soff = (unsigned)co * (unsigned)a.dy_cstride * 4u;
+          if (co < a.Cout) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(dYs + row * LDY + h * 64), 4,
+                                                       voff[h], soff, 0, 0);
+          } else if (b < 2) {
+            dYs[row * LDY + lane] = 0.f;
+            dYs[row * LDY + 64 + lane] = 0.f;
+          }
+        }
+      }
+      // ---- X window ---------------------------------------------------------------------
+      {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.x + (long)n0 * a.x_nstride), 0, 0x80000000u, 0x00020000);
+        const int vt0 = ot0 * a.st - a.pt, vh0 = oh0 * a.sh - a.ph, vw0 = ow0 * a.sw - a.pw;
+#pragma unroll
+        for (int jj = 0; jj < PW; ++jj) {
+          const int j = lw + 4 * jj;
+          if (j * 64 + lane < a.plane) {     // exec-masked: rows are packed at planeP
+            const int n = n0 + wn_[jj], it = vt0 + wt_[jj], ih = vh0 + wh_[jj], iw = vw0 + ww_[jj];
+            const bool ok = n < a.N && it >= 0 && ih >= 0 && iw >= 0 && it < a.Ti && ih < a.Hi &&
+                            iw < a.Wi;
+            const unsigned voff =
+                ok ? (unsigned)(((long)wn_[jj] * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4)
+                   : W2_OOB;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(Xs + c * planeP + j * 64), 4, voff,
+                                                       (unsigned)c * (unsigned)a.x_cstride * 4u, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+      __syncthreads();                      // barrier b
+    }
+    return;
+  }
+
+  // ================================ matrix waves ================================
+  const int half = lane >> 5, l31 = lane & 31;
+  int abase[2], jb[NJB];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) abase[mb] = (mb * 32 + l31) * LDY + wave * (BP / 4) + half;
+#pragma unroll
+  for (int nb = 0; nb < NJB; ++nb) {
+    int j = nb * 32 + l31;
+    if (j >= J) j = J - 1;                 // pad columns: computed, never stored
+    const int c = j / TAPS, tap = j - c * TAPS;
+    jb[nb] = BMt * LDY + c * planeP + (tap / KW) * a.WW + (tap % KW) + half * a.sw;
+  }
+  f32x16 acc[2][NJB];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NJB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  auto wo_of = [&](int s) {              // window offset of this wave's position 2s
+    const int p0 = wave * (BP / 4) + 2 * s;
+    const int tw = p0 & ((1 << lW) - 1);
+    const int th = (p0 >> lW) & ((1 << a.lTH) - 1);
+    const int tt = (p0 >> lWH) & ((1 << a.lTT) - 1);
+    const int tn = p0 >> lWHT;
+    return tn * a.plane1 + ((tt * a.st) * a.WH + th * a.sh) * a.WW + tw * a.sw;
+  };
+
+  for (int b = 0; b < nbox; ++b) {
+    const float* cur = smem + (b & 1) * stage_floats;
+    __syncthreads();   // barrier b
+    float av[2][2], bv[2][NJB];
+    auto fetch = [&](int s, float (&A)[2], float (&B)[NJB]) {
+      const int wo = wo_of(s);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) A[mb] = cur[abase[mb] + 2 * s];
+#pragma unroll
+      for (int nb = 0; nb < NJB; ++nb) B[nb] = cur[jb[nb] + wo];
+    };
+    fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      if (s + 1 < STEPS) fetch(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < NJB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mb], bv[s & 1][nb],
+                                                             acc[mb][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // partial tile of this wave: slice (split*4 + wave) of part[S*4][Cout][J]
+  float* out = a.part + ((long)split * 4 + wave) * a.Cout * J;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co0 + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int nb = 0; nb < NJB; ++nb) {
+          const int j = nb * 32 + l31;
+          if (j < J) out[(long)co * J + j] = acc[mb][nb][i];
+        }
+      }
+    }
+}
+
 // dW[co][ci*ci_stride' ...] = sum_s part[s][e]; destination may be a tap slice of a
 // larger stencil (r50 stem): e = co*J + ci*taps + tap ->
 // dst[co*co_stride + ci*ci_stride + tap_base + tap].
@@ -483,6 +673,35 @@ struct WPlan {
 };
 
 // tile of the v2 kernel for a stencil: returns variant id or 0
+// stem: (1,7,7) over 3 channels -> conv_wgrad_stem_kernel; fills the v2 plan fields
+int pick_stem(const coclr_conv_desc* d, WPlan* w) {
+  if (!(d->kt == 1 && d->kh == 7 && d->kw == 7 && d->Cin == 3)) return 0;
+  ConvPlan& p = w->p2;
+  conv_normalise(d, &p);
+  conv_pick_box(&p, 7, 1, 7, 7);
+  if (p.lTW < 1) return 0;
+  // LDS row pitch of the window == 7 (mod 32): the (kh,kw) offsets of 32 consecutive columns
+  // then hit distinct banks (the extra columns are loaded like any other, never read)
+  while ((p.WW & 31) != 7) ++p.WW;
+  p.plane1 = p.WT * p.WH * p.WW;
+  p.plane = p.plane1 << p.lTN;
+  if (cdiv(p.plane, 64) > 20) return 0;
+  w->planeP2 = p.plane | 1;
+  const size_t stage = ((size_t)64 * 129 + (size_t)3 * w->planeP2) * sizeof(float);
+  w->lds2 = 2 * stage;
+  if (w->lds2 > 160 * 1024) return 0;
+  const double lim = 2147483648.0;
+  if (((double)(1 << p.lTN) * d->x_nstride + (double)p.Cin * p.Ti * p.Hi * p.Wi) * 4.0 >= lim) return 0;
+  if (((double)(1 << p.lTN) * d->y_nstride + (double)p.Cout * p.To * p.Ho * p.Wo) * 4.0 >= lim) return 0;
+  w->mt2 = cdiv(p.Cout, 64);
+  w->ct2 = 1;
+  int S = 256 / w->mt2;                 // one 512-thread workgroup per CU
+  if (S > p.ntiles / 2) S = p.ntiles / 2;
+  if (S < 1) S = 1;
+  w->S2 = S;
+  return 9;
+}
+
 int pick_v2(const coclr_conv_desc* d, WPlan* w) {
   const int kt = d->kt, kh = d->kh, kw = d->kw;
   int MB = 1, NB = 1, id = 0;
@@ -525,6 +744,8 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
 int plan_wgrad(const coclr_conv_desc* d, WPlan* w) {
   if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return COCLR_EINVAL;
   if (d->dt != 1 || d->dh != 1 || d->dw != 1) return COCLR_EINVAL;
+  w->v2 = pick_stem(d, w);
+  if (w->v2) return 0;
   w->v2 = pick_v2(d, w);
   if (w->v2) return 0;
   ConvPlan& p = w->p;
@@ -592,7 +813,8 @@ extern "C" int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* e
   WPlan w;
   int rc = plan_wgrad(d, &w);
   if (rc) return rc;
-  *elems = (int64_t)(w.v2 ? w.S2 : w.S) * d->Cout * d->Cin * d->kt * d->kh * d->kw;
+  *elems = (int64_t)(w.v2 ? w.S2 * (w.v2 == 9 ? 4 : 1) : w.S) * d->Cout * d->Cin * d->kt * d->kh *
+           d->kw;
   return 0;
 }
 
@@ -631,10 +853,24 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
       case 3: rc = launch_wgrad2<7, 1, 1, 1, 1, 4>(a, w, stream); break;
       case 4: rc = launch_wgrad2<1, 1, 1, 2, 2, 2>(a, w, stream); break;
       case 5: rc = launch_wgrad2<1, 1, 1, 1, 1, 2>(a, w, stream); break;
+      case 9: {
+        auto kern = conv_wgrad_stem_kernel<7, 7, 3, 20>;
+        static bool attr_done = false;
+        if (!attr_done) {
+          COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              160 * 1024));
+          attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(w.S2, 1, w.mt2), dim3(512), w.lds2, stream, a);
+        COCLR_LAUNCH_CHECK();
+        rc = 0;
+        break;
+      }
       default: rc = COCLR_EINVAL;
     }
     if (rc) return rc;
-    S_used = w.S2;
+    S_used = w.S2 * (w.v2 == 9 ? 4 : 1);
   } else {
     const ConvPlan& p = w.p;
     WgradArgs a;
