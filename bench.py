@@ -203,6 +203,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+    t_host = time.perf_counter() - t0       # host enqueue time (no sync inside the loop)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -245,6 +246,7 @@ def main():
                        "excluded_caller_work": "accuracy meters/.item() syncs, dataloader+H2D",
                        "final_loss": round(final_loss, 4)},
             "roofline": roof, "step_roofline": step_view,
+            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 2),
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)

@@ -101,6 +101,10 @@ def load():
     return lib
 
 
-def check(rc, what):
+def check(rc, what, detail=None):
+    """`detail` (e.g. a geometry object) is only formatted when the call failed: these wrappers
+    run ~1500 times per training step."""
     if rc != 0:
+        if detail is not None:
+            what = "%s %s" % (what, detail)
         raise HipLibraryError("coclr_amd: %s failed with hipError %d" % (what, rc))

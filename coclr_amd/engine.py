@@ -17,12 +17,14 @@ What that buys on MI355X:
   * the launch sequence is static per input shape (hipGraph-capturable)
 """
 import os
+import weakref
 
 import torch
 
 from . import ops
 
 
+_PACK_STORE = {}      # id(weight) -> (weakref, {use -> packed buffer})
 WGRAD_STREAM = os.environ.get("COCLR_WGRAD_STREAM", "1") != "0"
 # Inception branches on their own streams: correct (GPU tier passes with it on) but SLOWER on
 # MI355X -- 47.3 vs 43.3 ms/step: ~160 fork/join points per step cost more in cross-queue
@@ -207,6 +209,24 @@ class Run:
             self._side_used = False
 
     # -- weight packing ------------------------------------------------------------
+    def _packed_buffer(self, owner, tag, n, zero):
+        """Packed-operand buffer that lives with the weight tensor `owner` (one per use and per
+        stream): re-packed every run, never re-allocated.  Safe because a given encoder always
+        runs on the same stream, so the re-pack is ordered after the previous run's reads."""
+        store = _PACK_STORE.get(id(owner))
+        if store is None or store[0]() is not owner:
+            store = _PACK_STORE[id(owner)] = (weakref.ref(owner), {})
+            if len(_PACK_STORE) > 4096:
+                for k_ in [k_ for k_, v_ in _PACK_STORE.items() if v_[0]() is None]:
+                    del _PACK_STORE[k_]
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        key = (tag, n, stream, self.device)
+        buf = store[1].get(key)
+        if buf is None:
+            buf = (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.device)
+            store[1][key] = buf
+        return buf
+
     def pack(self, w, transpose, kt_slice=None, taps=None, tap_base=0, tap_step=1):
         """[Cout][Cin][taps] -> [taps][Cin'][Cout'] (or the dgrad operand).  kt_slice picks
         one temporal slice of the stencil; (taps, tap_base, tap_step) an arithmetic subset."""
@@ -218,7 +238,7 @@ class Run:
         else:
             taps, base = kh * kw, kt_slice * kh * kw
         n = ops.conv_packed_size(cin, cout, taps, transpose)
-        packed = self.empty(n)
+        packed = self._packed_buffer(w, (bool(transpose), taps, base, tap_step), n, False)
         ops.conv_pack_weights(w, packed, cout, cin, taps, cin * kt * kh * kw, kt * kh * kw, base,
                               transpose, tap_step)
         return packed
@@ -229,7 +249,9 @@ class Run:
         cin = weights[0].shape[1]
         ctot = sum(w.shape[0] for w in weights)
         n = ops.conv_packed_size(cin, ctot, 1, transpose)
-        packed = torch.zeros(n, dtype=torch.float32, device=self.device)
+        # zero padding is written once, when the buffer is created; every run rewrites exactly
+        # the real sub-blocks
+        packed = self._packed_buffer(weights[0], ("cat", bool(transpose), ctot), n, True)
         c0 = 0
         for w in weights:
             cout = w.shape[0]
@@ -246,6 +268,20 @@ class Run:
 # ---------------------------------------------------------------------------------
 # conv (+ BatchNorm) (+ residual) (+ ReLU)
 # ---------------------------------------------------------------------------------
+
+_SLICED = {}
+
+
+def _sliced_geoms(N, Cin, Cout, idim, k, s, p):
+    """(5,7,7) stem as one (1,7,7) launch per temporal tap, all writing the full output."""
+    key = (N, Cin, Cout, tuple(idim), k, s, p)
+    g = _SLICED.get(key)
+    if g is None:
+        odim = ops.ConvGeom(N, Cin, Cout, idim, k, s, p).odim
+        g = _SLICED[key] = [ops.ConvGeom(N, Cin, Cout, idim, (1, k[1], k[2]), s,
+                                         (p[0] - t, p[1], p[2]), odim=odim) for t in range(k[0])]
+    return g
+
 
 def _is_plain_pointwise(k, s):
     return k == (1, 1, 1) and s != (1, 1, 1)
@@ -281,11 +317,9 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
 
     sliced = k[0] > 3 and k[1] > 1          # (5,7,7) stem: one launch per temporal tap
     if sliced:
-        geoms = [ops.ConvGeom(N, Cin, Cout, idim, (1, k[1], k[2]), s, (p[0] - t, p[1], p[2]),
-                              odim=ops.ConvGeom(N, Cin, Cout, idim, k, s, p).odim)
-                 for t in range(k[0])]
+        geoms = _sliced_geoms(N, Cin, Cout, idim, k, s, p)
     else:
-        geoms = [ops.ConvGeom(N, Cin, Cout, idim, k, s, p)]
+        geoms = [ops.conv_geom(N, Cin, Cout, idim, k, s, p)]
     odim = geoms[0].odim
     want_y = training or run.save or residual is not None
 
@@ -399,7 +433,7 @@ def pointwise_group(run, x, units):
     widths = [conv.weight.shape[0] for conv, _, _ in units]
     Ccat = sum(widths)
     weights = [conv.weight for conv, _, _ in units]
-    geom = ops.ConvGeom(N, Cin, Ccat, idim, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    geom = ops.conv_geom(N, Cin, Ccat, idim, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     xv = x.view()
     y = run.empty(N, Ccat, *idim)
     ntiles = geom.ntiles()
@@ -467,7 +501,7 @@ def pointwise_group(run, x, units):
 def max_pool(run, x, kernel, stride, padding):
     """nn.MaxPool3d (backbone/s3dg.py:105,151,162,173,190; resnet_2d3d.py:141)."""
     N, Cc = x.shape[0], x.shape[1]
-    g = ops.PoolGeom(N, Cc, x.shape[2:], _triple(kernel), _triple(stride), _triple(padding))
+    g = ops.pool_geom(N, Cc, x.shape[2:], _triple(kernel), _triple(stride), _triple(padding))
     y = run.empty(N, Cc, *g.odim)
     need = run.needs_grad(x)
     idx = run.empty(N, Cc, *g.odim, dtype=torch.int32) if need else None
@@ -562,7 +596,9 @@ def _dense5(t):
 
 def run_module(module, x, **kwargs):
     """Forward `module` (anything with `_emit(run, val, **kw)`) on x."""
-    params = [p for p in module.parameters()]
+    params = module.__dict__.get("_coclr_params")
+    if params is None:
+        params = module.__dict__["_coclr_params"] = list(module.parameters())
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
         return EngineFn.apply(module, kwargs, x, *params)
     run = Run(x.device, save=False)

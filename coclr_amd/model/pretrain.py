@@ -284,30 +284,34 @@ class InfoNCE(nn.Module):
 
     # -- momentum encoder ---------------------------------------------------------
     def _build_momentum_table(self):
-        rows, sig = [], []
-        for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+        rows = []
+        pq_list, pk_list = list(self.encoder_q.parameters()), list(self.encoder_k.parameters())
+        for pq, pk in zip(pq_list, pk_list):
             if not (pq.is_contiguous() and pk.is_contiguous()):
                 raise RuntimeError("coclr_amd: encoder parameters must be contiguous")
-            sig.append((pq.data_ptr(), pk.data_ptr()))
             n = pk.numel()
             for off in range(0, n, _CHUNK):
                 rows.append((pk.data_ptr() + 4 * off, pq.data_ptr() + 4 * off,
                              min(_CHUNK, n - off)))
-        dev = next(self.encoder_k.parameters()).device
+        dev = pk_list[0].device
         table = torch.tensor(rows, dtype=torch.int64).to(dev)
-        self._momentum_table = (tuple(sig), table, len(rows))
+        self._momentum_table = (self._momentum_sig(pq_list, pk_list), table, len(rows), pq_list,
+                                pk_list)
+
+    @staticmethod
+    def _momentum_sig(pq_list, pk_list):
+        # storage moves (.cuda(), .to()) re-create every parameter's data at once
+        return (pq_list[0].data_ptr(), pq_list[-1].data_ptr(), pk_list[0].data_ptr(),
+                pk_list[-1].data_ptr(), len(pq_list))
 
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
         '''p_k <- p_k * m + p_q * (1 - m) for every parameter pair, one launch.'''
-        sig = tuple((pq.data_ptr(), pk.data_ptr())
-                    for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()))
-        if self._momentum_table is None or self._momentum_table[0] != sig:
+        mt = self._momentum_table
+        if mt is None or mt[0] != self._momentum_sig(mt[3], mt[4]):
             self._build_momentum_table()
-        _, table, n = self._momentum_table
-        pairs = [(pk.data, pq.data) for pq, pk in zip(self.encoder_q.parameters(),
-                                                      self.encoder_k.parameters())]
-        ops.momentum_update(table, n, float(self.m), float(1. - self.m), pairs=pairs)
+            mt = self._momentum_table
+        ops.momentum_update(mt[1], mt[2], float(self.m), float(1. - self.m), pairs=(mt[4], mt[3]))
 
     # -- queue ---------------------------------------------------------------------
     @torch.no_grad()

@@ -13,6 +13,17 @@ from . import _lib
 from ._lib import ConvDesc, PoolDesc
 
 
+_HANDLE = None
+
+
+def _L():
+    """ctypes handle, resolved once (every wrapper below runs ~1500 times per step)."""
+    global _HANDLE
+    if _HANDLE is None:
+        _HANDLE = _lib.load()
+    return _HANDLE
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -118,8 +129,8 @@ class ConvGeom:
         v = self._cache.get("ntiles")
         if v is None:
             out = C.c_int32(0)
-            _lib.check(_lib.load().coclr_conv3d_ntiles(C.byref(self.desc), C.byref(out)),
-                       "conv3d_ntiles %s" % self)
+            _lib.check(_L().coclr_conv3d_ntiles(C.byref(self.desc), C.byref(out)),
+                       "conv3d_ntiles", self)
             v = self._cache["ntiles"] = out.value
         return v
 
@@ -127,14 +138,37 @@ class ConvGeom:
         v = self._cache.get("wgws")
         if v is None:
             out = C.c_int64(0)
-            _lib.check(_lib.load().coclr_conv3d_wgrad_workspace(C.byref(self.desc), C.byref(out)),
-                       "conv3d_wgrad_workspace %s" % self)
+            _lib.check(_L().coclr_conv3d_wgrad_workspace(C.byref(self.desc), C.byref(out)),
+                       "conv3d_wgrad_workspace", self)
             v = self._cache["wgws"] = out.value
         return v
 
     def __repr__(self):
         return "ConvGeom(N=%d, %d->%d, in=%s, out=%s, k=%s, s=%s, p=%s, d=%s)" % (
             self.N, self.Cin, self.Cout, self.idim, self.odim, self.k, self.s, self.p, self.d)
+
+
+_GEOMS = {}
+
+
+def conv_geom(N, Cin, Cout, idim, k, s, p):
+    """Shared, cached ConvGeom (its ntiles / dgrad / phase plans are computed once): the engine
+    asks for the same ~80 geometries every step."""
+    key = (N, Cin, Cout, tuple(idim), tuple(k), tuple(s), tuple(p))
+    g = _GEOMS.get(key)
+    if g is None:
+        if len(_GEOMS) > 8192:
+            _GEOMS.clear()
+        g = _GEOMS[key] = ConvGeom(N, Cin, Cout, idim, k, s, p)
+    return g
+
+
+def pool_geom(N, Cc, idim, k, s, p):
+    key = ("pool", N, Cc, tuple(idim), tuple(k), tuple(s), tuple(p))
+    g = _GEOMS.get(key)
+    if g is None:
+        g = _GEOMS[key] = PoolGeom(N, Cc, idim, k, s, p)
+    return g
 
 
 class PoolGeom:
@@ -153,16 +187,28 @@ class PoolGeom:
 
 # ---- convolution ---------------------------------------------------------------
 
+_PACKED = {}
+
+
 def conv_packed_size(cin, cout, taps, transpose):
+    key = (cin, cout, taps, bool(transpose))
+    v = _PACKED.get(key)
+    if v is not None:
+        return v
+    v = _PACKED[key] = _conv_packed_size(cin, cout, taps, transpose)
+    return v
+
+
+def _conv_packed_size(cin, cout, taps, transpose):
     out = C.c_int64(0)
-    _lib.check(_lib.load().coclr_conv_packed_size(cin, cout, taps, int(transpose), C.byref(out)),
+    _lib.check(_L().coclr_conv_packed_size(cin, cout, taps, int(transpose), C.byref(out)),
                "conv_packed_size")
     return out.value
 
 
 def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose,
                       tap_step=1, row0=0, rows_total=0, col0=0, cols_total=0):
-    _lib.check(_lib.load().coclr_conv_pack_weights(
+    _lib.check(_L().coclr_conv_pack_weights(
         _p(w), _p(packed), cout, cin, taps, co_stride, ci_stride, tap_base, tap_step,
         int(transpose), row0, rows_total, col0, cols_total, _stream()), "conv_pack_weights")
 
@@ -173,18 +219,18 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(y, "y")
     d.Nx = x.shape[0]
-    _lib.check(_lib.load().coclr_conv3d_fwd(
+    _lib.check(_L().coclr_conv3d_fwd(
         C.byref(d), _p(x), _p(w_packed), _p(y), _p(stats), _p(bias), _p(ep_scale), _p(ep_shift),
-        _p(n_index, torch.int64), int(relu), int(accumulate), _stream()), "conv3d_fwd %s" % geom)
+        _p(n_index, torch.int64), int(relu), int(accumulate), _stream()), "conv3d_fwd", geom)
 
 
 def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accumulate=False):
     d = geom.desc
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(dy, "dy")
-    _lib.check(_lib.load().coclr_conv3d_wgrad(
+    _lib.check(_L().coclr_conv3d_wgrad(
         C.byref(d), _p(x), _p(dy), _p(dw), _p(workspace), co_stride, ci_stride, tap_base,
-        int(accumulate), _stream()), "conv3d_wgrad %s" % geom)
+        int(accumulate), _stream()), "conv3d_wgrad", geom)
 
 
 # ---- batch norm ------------------------------------------------------------------
@@ -195,14 +241,14 @@ def bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var
     this call finalises channels [c0, c0+C_)."""
     c_total = C_ if c_total is None else c_total
     base = _p(stats)
-    _lib.check(_lib.load().coclr_bn_finalize(
+    _lib.check(_L().coclr_bn_finalize(
         base + 4 * c0 * ntiles, base + 4 * (c_total + c0) * ntiles, C_, ntiles, float(count),
         _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(nbt, torch.int64), momentum, eps,
         _p(mean), _p(invstd), _p(scale), _p(shift), _stream()), "bn_finalize")
 
 
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps, C_, mean, invstd, scale, shift):
-    _lib.check(_lib.load().coclr_bn_eval_affine(
+    _lib.check(_L().coclr_bn_eval_affine(
         _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C_, _p(mean), _p(invstd),
         _p(scale), _p(shift), _stream()), "bn_eval_affine")
 
@@ -210,7 +256,7 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps, C_, mean, invstd
 def bn_act_apply(y, scale, shift, residual, z, relu):
     N, C_, T, H, W = y.shape
     S = T * H * W
-    _lib.check(_lib.load().coclr_bn_act_apply(
+    _lib.check(_L().coclr_bn_act_apply(
         _p(y), _p(scale), _p(shift), _p(residual), _p(z), N, C_, S, _chk5(y, "y"), _chk5(z, "z"),
         _chk5(residual, "residual") if residual is not None else 0, int(relu), _stream()),
         "bn_act_apply")
@@ -227,7 +273,7 @@ def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dga
     S = T * H * W
     if sums_ws.numel() < 2 * C_ * N:
         raise ValueError("coclr_amd: bn_act_backward workspace too small")
-    _lib.check(_lib.load().coclr_bn_act_backward(
+    _lib.check(_L().coclr_bn_act_backward(
         _p(dz), _p(y), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd),
         _p(sums_ws, torch.float64), _p(dy), _p(dres), _p(dgamma), _p(dbeta), N, C_, S,
         _chk5(dz, "dz"), _chk5(y, "y"), _chk5(dy, "dy"), _chk5(z, "z") if z is not None else 0,
@@ -241,26 +287,26 @@ def maxpool_fwd(geom, x, y, indices=None):
     d = geom.desc
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(y, "y")
-    _lib.check(_lib.load().coclr_maxpool3d_fwd(C.byref(d), _p(x), _p(y),
+    _lib.check(_L().coclr_maxpool3d_fwd(C.byref(d), _p(x), _p(y),
                                                _p(indices, torch.int32), _stream()),
                "maxpool3d_fwd")
 
 
 def maxpool_bwd(geom, dy, indices, dx, accumulate=False):
-    _lib.check(_lib.load().coclr_maxpool3d_bwd(
+    _lib.check(_L().coclr_maxpool3d_bwd(
         C.byref(geom.desc), _p(dy), _p(indices, torch.int32), _p(dx), _chk5(dy, "dy"),
         _chk5(dx, "dx"), int(accumulate), _stream()), "maxpool3d_bwd")
 
 
 def global_avgpool_fwd(x, y):
     planes = x.shape[0] * x.shape[1]
-    _lib.check(_lib.load().coclr_global_avgpool_fwd(_p(x), _p(y), planes, x.numel() // planes,
+    _lib.check(_L().coclr_global_avgpool_fwd(_p(x), _p(y), planes, x.numel() // planes,
                                                     _stream()), "global_avgpool_fwd")
 
 
 def global_avgpool_bwd(dy, dx):
     planes = dx.shape[0] * dx.shape[1]
-    _lib.check(_lib.load().coclr_global_avgpool_bwd(_p(dy), _p(dx), planes, dx.numel() // planes,
+    _lib.check(_L().coclr_global_avgpool_bwd(_p(dy), _p(dx), planes, dx.numel() // planes,
                                                     _stream()), "global_avgpool_bwd")
 
 
@@ -268,72 +314,72 @@ def global_avgpool_bwd(dy, dx):
 
 def gemm_workspace(M, N, K, splits):
     out = C.c_int64(0)
-    _lib.check(_lib.load().coclr_gemm_workspace(M, N, K, splits, C.byref(out)), "gemm_workspace")
+    _lib.check(_L().coclr_gemm_workspace(M, N, K, splits, C.byref(out)), "gemm_workspace")
     return out.value
 
 
 def gemm(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha=1.0, relu=False, accumulate=False,
          splits=1, workspace=None):
-    _lib.check(_lib.load().coclr_gemm(
+    _lib.check(_L().coclr_gemm(
         _p(a), sam, sak, _p(b), sbk, sbn, _p(c), ldc, _p(bias), M, N, K, alpha, int(relu),
         int(accumulate), splits, _p(workspace), _stream()), "gemm")
 
 
 def l2norm_fwd(x, y, inv_norm, eps=1e-12):
     rows, D = x.shape
-    _lib.check(_lib.load().coclr_l2norm_fwd(_p(x), _p(y), _p(inv_norm), rows, D, eps, _stream()),
+    _lib.check(_L().coclr_l2norm_fwd(_p(x), _p(y), _p(inv_norm), rows, D, eps, _stream()),
                "l2norm_fwd")
 
 
 def l2norm_bwd(dy, y, inv_norm, dx):
     rows, D = y.shape
-    _lib.check(_lib.load().coclr_l2norm_bwd(_p(dy), _p(y), _p(inv_norm), _p(dx), rows, D,
+    _lib.check(_L().coclr_l2norm_bwd(_p(dy), _p(y), _p(inv_norm), _p(dx), rows, D,
                                             _stream()), "l2norm_bwd")
 
 
 def nce_logits_fwd(q, k, queue, logits, T):
     B, D = q.shape
     K = queue.shape[1]
-    _lib.check(_lib.load().coclr_nce_logits_fwd(_p(q), _p(k), _p(queue), _p(logits), B, D, K, T,
+    _lib.check(_L().coclr_nce_logits_fwd(_p(q), _p(k), _p(queue), _p(logits), B, D, K, T,
                                                 _stream()), "nce_logits_fwd")
 
 
 def nce_logits_bwd(dlogits, k, queue, dq, workspace, T, splits):
     B, D = dq.shape
     K = queue.shape[1]
-    _lib.check(_lib.load().coclr_nce_logits_bwd(_p(dlogits), _p(k), _p(queue), _p(dq),
+    _lib.check(_L().coclr_nce_logits_bwd(_p(dlogits), _p(k), _p(queue), _p(dq),
                                                 _p(workspace), B, D, K, T, splits, _stream()),
                "nce_logits_bwd")
 
 
 def momentum_update(table, nchunks, m, one_minus_m, pairs=None):
-    """`pairs` (the (dst, src) tensors the pointer table was built from) is not used by the
+    """`pairs` = (dst tensors, src tensors) the pointer table was built from: not used by the
     kernel; callers pass it so the tensors stay referenced while the launch is queued."""
-    _lib.check(_lib.load().coclr_momentum_update(_p(table, torch.int64), nchunks, m, one_minus_m,
+    _lib.check(_L().coclr_momentum_update(_p(table, torch.int64), nchunks, m, one_minus_m,
                                                  _stream()), "momentum_update")
 
 
 def queue_enqueue(queue, keys, ptr):
     D, K = queue.shape
     BW = keys.shape[0]
-    _lib.check(_lib.load().coclr_queue_enqueue(_p(queue), _p(keys), D, K, BW,
+    _lib.check(_L().coclr_queue_enqueue(_p(queue), _p(keys), D, K, BW,
                                                _p(ptr, torch.int64), _stream()), "queue_enqueue")
 
 
 def queue_fill_i64(queue, vals, const_val, BW, ptr):
-    _lib.check(_lib.load().coclr_queue_fill_i64(
+    _lib.check(_L().coclr_queue_fill_i64(
         _p(queue, torch.int64), _p(vals, torch.int64), const_val, queue.shape[0], BW,
         _p(ptr, torch.int64), _stream()), "queue_fill_i64")
 
 
 def queue_advance(ptr, BW, K):
-    _lib.check(_lib.load().coclr_queue_advance(_p(ptr, torch.int64), BW, K, _stream()),
+    _lib.check(_L().coclr_queue_advance(_p(ptr, torch.int64), BW, K, _stream()),
                "queue_advance")
 
 
 def positive_mask(sim, src, names, mask, topk):
     B, K1 = mask.shape
-    _lib.check(_lib.load().coclr_positive_mask(
+    _lib.check(_L().coclr_positive_mask(
         _p(sim), _p(src, torch.int64), _p(names, torch.int64), _p(mask, torch.uint8), B, K1 - 1,
         topk, _stream()), "positive_mask")
 
@@ -346,19 +392,19 @@ def gather_rows(inp, idx, out):
         in_stride = inp.stride(0) if inp.shape[0] > 1 else row_elems
     else:
         raise ValueError("coclr_amd: gather_rows needs dense source rows")
-    _lib.check(_lib.load().coclr_gather_rows(_p(inp), _p(idx, torch.int64), _p(out), rows,
+    _lib.check(_L().coclr_gather_rows(_p(inp), _p(idx, torch.int64), _p(out), rows,
                                              row_elems, max(in_stride, row_elems), _stream()),
                "gather_rows")
 
 
 def relu_fwd(x, y):
-    _lib.check(_lib.load().coclr_relu_fwd(_p(x), _p(y), x.numel(), _stream()), "relu_fwd")
+    _lib.check(_L().coclr_relu_fwd(_p(x), _p(y), x.numel(), _stream()), "relu_fwd")
 
 
 def relu_bwd(dy, y, dx):
-    _lib.check(_lib.load().coclr_relu_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream()), "relu_bwd")
+    _lib.check(_L().coclr_relu_bwd(_p(dy), _p(y), _p(dx), y.numel(), _stream()), "relu_bwd")
 
 
 def colsum(x, out):
     rows, cols = x.shape
-    _lib.check(_lib.load().coclr_colsum(_p(x), _p(out), rows, cols, _stream()), "colsum")
+    _lib.check(_L().coclr_colsum(_p(x), _p(out), rows, cols, _stream()), "colsum")

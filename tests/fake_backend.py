@@ -251,8 +251,8 @@ def nce_logits_bwd(dlogits, k, queue, dq, workspace, T, splits):
 def momentum_update(table, nchunks, m, one_minus_m, pairs=None):
     mf = torch.tensor(m, dtype=torch.float32)
     of = torch.tensor(one_minus_m, dtype=torch.float32)
-    for dst, src in pairs:
-        dst.copy_(dst * mf + src * of)
+    for dst, src in zip(*pairs):
+        dst.data.copy_(dst.data * mf + src.data * of)
 
 
 def queue_enqueue(queue, keys, ptr):
