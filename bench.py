@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--img-dim", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="intra-op threads of the CPU baseline (16 is the fastest on the 128-core "
+                         "GPU host: 8->2.67, 16->2.88, 32->2.77, 64->1.67, 128->0.78 clips/s)")
     return ap.parse_args()
 
 
@@ -107,6 +110,7 @@ def cpu_baseline(args):
     from oracle import coclr_oracle as orc
     from model.pretrain import InfoNCE
     B, K = 4, 2048
+    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     torch.manual_seed(0)
     model = InfoNCE(args.net, 128, K, 0.999, 0.07)
     sd = orc.training_state(model.state_dict())
@@ -220,13 +224,23 @@ def main():
         kms = timer.mean_ms()
         flops = 2.0 * B * 192 * 64 * 9 * tq * hq * hq          # algorithmic, per launch
         roof = None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.net == "s3d" and B == 32:
+            # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
+            # (counters cannot be read from inside the process)
+            tj = json.load(open(tpath))
+            traffic = {"bytes_per_launch": tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"],
+                       "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
+                       "source": tj["source"]}
         if kms:
             ach = flops / (kms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None,
-                    "kernel": "conv_igemm_kernel<1,3,3,CC=8,BM=64|128,BN=128> (Conv_2c.conv1 64->192, "
-                              "%dx%dx%d, N=%d)" % (tq, hq, hq, B),
+                    "traffic": traffic,
+                    "kernel": "conv_igemm_kernel<1,3,3,8,64,128,4> (Conv_2c.conv1 64->192, %dx%dx%d, "
+                              "N=%d; q and k launches, the k-encoder's overlap other streams)"
+                              % (tq, hq, hq, B),
                     "launches_timed": len(timer.events), "avg_launch_ms": round(kms, 4),
                     "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
         # whole-step view against both rooflines (91.46 GF, 2145 MB per clip)
