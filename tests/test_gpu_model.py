@@ -161,3 +161,38 @@ def test_select_backbone_contract():
     x = torch.randn(2, 3, 16, 64, 64).cuda()
     y = net.cuda()(x)
     assert y.shape == (2, 1024, 2, 2, 2)
+
+
+def test_graph_replay_matches_eager():
+    """From its third call on, a gradient-free encoder pass is replayed from a captured hipGraph
+    (model.pretrain._encode_graphed).  The same key encoder driven five times through the
+    graph path and through the eager path (identical copies, identical inputs, momentum update
+    as the captured prologue): keys, momentum-updated weights and BatchNorm running statistics
+    must agree bit for bit -- every kernel on this path is deterministic."""
+    import copy
+    import model.pretrain as product
+    gold = load_golden("infonce_s3d_small")
+    cfg = gold["cfg"]
+    base = build_model(cfg, product)
+    models = [copy.deepcopy(base).cuda().train() for _ in range(2)]
+    keys = [[], []]
+    for which, graphs in enumerate((True, False)):
+        m = models[which]
+        m._sync_buffers()
+        product._GRAPHS = graphs
+        try:
+            with torch.no_grad():
+                for step in range(5):
+                    blocks, _ = case_inputs(cfg, step % cfg["steps"])
+                    x2 = blocks[0][:, 1].cuda()
+                    idx = torch.randperm(x2.shape[0], generator=torch.Generator().manual_seed(step)).cuda()
+                    keys[which].append(m._encode_graphed(m.encoder_k, x2, idx,
+                                                         pre=m._momentum_update_key_encoder).clone())
+        finally:
+            product._GRAPHS = True
+    assert "graph" in models[0].__dict__["_graphs"][id(models[0].encoder_k)]
+    for a, b in zip(*keys):
+        assert torch.equal(a, b)
+    sd_g, sd_e = models[0].state_dict(), models[1].state_dict()
+    for k in sd_g:
+        assert torch.equal(sd_g[k], sd_e[k]), k

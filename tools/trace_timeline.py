@@ -41,3 +41,26 @@ for i in range(max(1, len(bounds) - 3), len(bounds)):
         cur_e = max(cur_e, e)
     gaps.sort(reverse=True)
     print("   largest gaps (us, next kernel):", [(round(g / 1e3, 1), n) for g, n in gaps[:6]])
+
+# ---- per-stream view of the last full step -------------------------------------------------
+t0, t1 = bounds[-2], bounds[-1]
+sel = [(s, e, st, n) for s, e, st, n in ev if s >= t0 and e <= t1]
+streams = sorted(set(st for _, _, st, _ in sel))
+print("\nlast step, per stream (ms relative to step start): first start, last end, busy, #kernels")
+for st in streams:
+    ks = [(s, e, n) for s, e, q, n in sel if q == st]
+    print("  stream %d: %.2f .. %.2f  busy %.2f  n=%d" % (st, (ks[0][0] - t0) / 1e6, (ks[-1][1] - t0) / 1e6,
+                                                        sum(e - s for s, e, n in ks) / 1e6, len(ks)))
+# 1 ms buckets: which streams are active
+import math
+nb = int(math.ceil((t1 - t0) / 1e6))
+print("per-ms activity (fraction of the ms each stream has a kernel running):")
+for b in range(nb):
+    lo, hi = t0 + b * 1e6, t0 + (b + 1) * 1e6
+    row = []
+    for st in streams:
+        busy = sum(max(0, min(e, hi) - max(s, lo)) for s, e, q, n in sel if q == st and e > lo and s < hi)
+        row.append("%3d%%" % (100 * busy / 1e6))
+    tops = [((min(e, hi) - max(s, lo)), n) for s, e, q, n in sel if e > lo and s < hi]
+    top = max(tops) if tops else (0, "-")
+    print("  %2d ms: %s   %s" % (b, " ".join(row), re.sub(r"<.*", "", top[1])[:40]))
