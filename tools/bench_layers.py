@@ -78,3 +78,21 @@ for name, c, k, s, p, idim in P:
     mbf = (x.numel() + 2 * y.numel()) * 4 / 1e6
     mbb = (x.numel() + 2 * y.numel()) * 4 / 1e6
     print("%-12s %9.1f | %8.3f %8.0f | %8.3f %8.0f" % (name, mbf, tf, mbf/tf, tb, mbb/tb))
+
+# ---- BatchNorm (HBM-bound): apply = 2|y| bytes, backward = 5|y| bytes -----------------------
+print()
+print("%-16s %9s | %8s %8s | %8s %8s" % ("bn unit", "|y| MB", "apply ms", "GB/s", "bwd ms", "GB/s"))
+for name, c, idim in [("Conv_1a.bn1", 64, (32, 64, 64)), ("Conv_1a.bn2", 64, (16, 64, 64)),
+                      ("Conv_2c.bn1", 192, (16, 32, 32)), ("Mixed_3c.out", 480, (16, 16, 16)),
+                      ("Mixed_4f.b1", 320, (8, 8, 8)), ("Mixed_5c.b1", 384, (4, 4, 4))]:
+    if only and not any(o in name for o in only): continue
+    y = torch.randn(B, c, *idim, device=dev)
+    z = torch.empty_like(y); dz = torch.randn_like(y); dy = torch.empty_like(y)
+    small = torch.rand(4, c, device=dev) + 0.5
+    dgb = torch.empty(2, c, device=dev)
+    sums = torch.empty(ops.bn_backward_workspace(B, c), dtype=torch.float64, device=dev)
+    ta = timeit(lambda: ops.bn_act_apply(y, small[2], small[3], None, z, True))
+    tb = timeit(lambda: ops.bn_act_backward(dz, y, None, small[2], small[3], small[0], small[1], sums, dy,
+                                            None, dgb[0], dgb[1], True, True))
+    mb = y.numel() * 4 / 1e6
+    print("%-16s %9.1f | %8.3f %8.0f | %8.3f %8.0f" % (name, mb, ta, 2 * mb / ta, tb, 5 * mb / tb))
