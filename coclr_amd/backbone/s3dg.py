@@ -11,9 +11,14 @@ ATen forward is never called.  Each module implements `_emit(run, val)`, which
 enqueues HIP kernels through coclr_amd.engine; `forward` wraps a whole
 (sub)network in a single autograd node.
 """
+import os
+
+import torch
 import torch.nn as nn
 
 from .. import engine
+
+SPLIT_STAGES = os.environ.get("COCLR_SPLIT_STAGES", "1") != "0"
 
 
 class _Emitter(nn.Module):
@@ -222,4 +227,20 @@ class S3D(_Emitter):
         x = self.block1._emit(run, x, n_index=n_index)
         for blk in (self.block2, self.block3, self.block4, self.block5):
             x = blk._emit(run, x)
+        return x
+
+    def forward(self, x, n_index=None):
+        """One autograd node per stage (block1..block5), like the reference's forward
+        (backbone/s3dg.py:211-217).  With gradients enabled this lets the gradients of the late
+        stages -- 216 of the 231 backbone tensors live in block3-5 -- reach DistributedDataParallel
+        while the early stages are still in backward: its per-parameter bucket copies and the
+        all-reduce then overlap the weight-gradient stream instead of forming a host-paced tail
+        after the whole backward."""
+        if not (torch.is_grad_enabled() and SPLIT_STAGES):
+            return engine.run_module(self, x, n_index=n_index) if n_index is not None \
+                else engine.run_module(self, x)
+        x = engine.run_module(self.block1, x, n_index=n_index) if n_index is not None \
+            else engine.run_module(self.block1, x)
+        for blk in (self.block2, self.block3, self.block4, self.block5):
+            x = engine.run_module(blk, x)
         return x
