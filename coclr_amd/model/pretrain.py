@@ -380,6 +380,16 @@ class InfoNCE(nn.Module):
         st.wait_stream(torch.cuda.current_stream(x.device))
         return st
 
+    def _query_requires_grad(self, x):
+        """Whether the query features will carry autograd history (the reference's
+        `in_train_mode = q.requires_grad`), known before the encoder runs."""
+        if not torch.is_grad_enabled():
+            return False
+        ps = self.encoder_q.__dict__.get("_coclr_plist")
+        if ps is None:
+            ps = self.encoder_q.__dict__["_coclr_plist"] = list(self.encoder_q.parameters())
+        return x.requires_grad or any(p.requires_grad for p in ps)
+
     @staticmethod
     def _join(st):
         if st is not None:
@@ -531,12 +541,14 @@ class InfoNCE(nn.Module):
         B = x1.shape[0]
 
         side = self._key_stream(x1)
-        q = self._encode(self.encoder_q, x1)
-        in_train_mode = q.requires_grad
-
+        in_train_mode = self._query_requires_grad(x1)    # == q.requires_grad (ref :157)
+        # key path first: it is one graph replay on the side stream, so both encoders start
+        # together instead of the key encoder waiting for the host to enqueue the query one
         with torch.no_grad(), torch.cuda.stream(side):
             k, k_all = self._encode_keys(
                 x2, pre=self._momentum_update_key_encoder if in_train_mode else None)
+        q = self._encode(self.encoder_q, x1)
+        assert q.requires_grad == in_train_mode
         self._join(side)
 
         logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
@@ -570,12 +582,14 @@ class UberNCE(InfoNCE):
         B = x1.shape[0]
 
         side = self._key_stream(x1)
-        q = self._encode(self.encoder_q, x1)
-        in_train_mode = q.requires_grad
-
+        in_train_mode = self._query_requires_grad(x1)    # == q.requires_grad (ref :157)
+        # key path first: it is one graph replay on the side stream, so both encoders start
+        # together instead of the key encoder waiting for the host to enqueue the query one
         with torch.no_grad(), torch.cuda.stream(side):
             k, k_all = self._encode_keys(
                 x2, pre=self._momentum_update_key_encoder if in_train_mode else None)
+        q = self._encode(self.encoder_q, x1)
+        assert q.requires_grad == in_train_mode
         self._join(side)
 
         logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
@@ -638,9 +652,7 @@ class CoCLR(InfoNCE):
         B = x1.shape[0]
 
         side = self._key_stream(x1)
-        q = self._encode(self.encoder_q, x1)
-        in_train_mode = q.requires_grad
-
+        in_train_mode = self._query_requires_grad(x1)    # == q.requires_grad (ref :157)
         with torch.no_grad(), torch.cuda.stream(side):
             k, k_all = self._encode_keys(
                 x2, pre=self._momentum_update_key_encoder if in_train_mode else None)
@@ -650,6 +662,8 @@ class CoCLR(InfoNCE):
             if ident is None or ident.shape[0] != B or ident.device != f2.device:
                 ident = self.__dict__["_ident_idx"] = torch.arange(B, device=f2.device)
             kf = self._encode_graphed(self.sampler, f2, ident)
+        q = self._encode(self.encoder_q, x1)
+        assert q.requires_grad == in_train_mode
         self._join(side)
 
         logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
