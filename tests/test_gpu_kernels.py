@@ -189,7 +189,10 @@ def test_sliced_stem_5x7x7():
 
 @pytest.mark.parametrize("shape,relu,res", [((4, 24, 4, 8, 8), True, False),
                                             ((3, 10, 3, 5, 7), True, True),
-                                            ((2, 64, 2, 4, 4), False, False)])
+                                            ((2, 64, 2, 4, 4), False, False),
+                                            # N*S > 16384: the streaming two-pass kernels
+                                            ((4, 8, 8, 32, 32), True, False),
+                                            ((3, 6, 7, 30, 31), True, True)])
 def test_batchnorm_train_fwd_bwd(shape, relu, res):
     from coclr_amd import ops
     torch.manual_seed(4)
