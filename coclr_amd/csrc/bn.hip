@@ -74,10 +74,12 @@ bn_act_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale
                     const float* __restrict__ shift, const float* __restrict__ res, float* z,
                     int N, int C, int S, long y_nstride, long z_nstride, long res_nstride,
                     int relu) {
-  const int planes = N * C;
-  for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
-    const int n = pl / C, c = pl - n * C;
-    const float sc = scale[c], sf = shift[c];
+  // blockIdx.y = (sample group, channel): a block walks the samples n = group, group + nsg, ...
+  // of ONE channel, so small planes (S = 64..512 in the last stages) still give every block a
+  // few thousand elements instead of one 2 KB plane
+  const int c = blockIdx.y % C, sg = blockIdx.y / C, nsg = gridDim.y / C;
+  const float sc = scale[c], sf = shift[c];
+  for (int n = sg; n < N; n += nsg) {
     const float* yp = y + (long)n * y_nstride + (long)c * S;
     float* zp = z + (long)n * z_nstride + (long)c * S;
     const float* rp = res ? res + (long)n * res_nstride + (long)c * S : nullptr;
@@ -184,33 +186,33 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
                         long y_nstride, long dy_nstride, long z_nstride, long dres_nstride,
                         int relu, int dres_accumulate) {
   __shared__ double tot[2];
-  const int planes = N * C;
-  for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
-    const int n = pl / C, c = pl - n * C;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      double a0 = 0.0, a1 = 0.0;
-      for (int g = threadIdx.x; g < groups; g += 64) {
-        a0 += sums[((long)c * groups + g) * 2];
-        a1 += sums[((long)c * groups + g) * 2 + 1];
-      }
-      a0 = wave_sum_d(a0);
-      a1 = wave_sum_d(a1);
-      if (threadIdx.x == 0) { tot[0] = a0; tot[1] = a1; }
+  // blockIdx.y = (sample group, channel); the partial sums of the channel are folded once per
+  // block, then the block walks its samples
+  const int c = blockIdx.y % C, sgrp = blockIdx.y / C, nsg = gridDim.y / C;
+  if (threadIdx.x < 64) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int g = threadIdx.x; g < groups; g += 64) {
+      a0 += sums[((long)c * groups + g) * 2];
+      a1 += sums[((long)c * groups + g) * 2 + 1];
     }
-    __syncthreads();
-    const double sg = tot[0], sgx = tot[1];
-    const float sc = scale[c], sf = shift[c];
-    float A = sc, B = 0.f, D = 0.f;
-    if (training) {
-      const float mg = (float)(sg / count), mgx = (float)(sgx / count);
-      B = -sc * invstd[c] * mgx;
-      D = sc * (mean[c] * invstd[c] * mgx - mg);
-    }
-    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-      if (dgamma) dgamma[c] = (float)sgx;
-      if (dbeta) dbeta[c] = (float)sg;
-    }
+    a0 = wave_sum_d(a0);
+    a1 = wave_sum_d(a1);
+    if (threadIdx.x == 0) { tot[0] = a0; tot[1] = a1; }
+  }
+  __syncthreads();
+  const double sg = tot[0], sgx = tot[1];
+  const float sc = scale[c], sf = shift[c];
+  float A = sc, B = 0.f, D = 0.f;
+  if (training) {
+    const float mg = (float)(sg / count), mgx = (float)(sgx / count);
+    B = -sc * invstd[c] * mgx;
+    D = sc * (mean[c] * invstd[c] * mgx - mg);
+  }
+  if (sgrp == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (dgamma) dgamma[c] = (float)sgx;
+    if (dbeta) dbeta[c] = (float)sg;
+  }
+  for (int n = sgrp; n < N; n += nsg) {
     const float* dzp = dz + (long)n * dz_nstride + (long)c * S;
     const float* yp = y + (long)n * y_nstride + (long)c * S;
     const float* zp = z ? z + (long)n * z_nstride + (long)c * S : nullptr;
@@ -257,16 +259,30 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
   }
 }
 
-inline dim3 plane_grid(int planes, int S) {
+// Grid for the streaming kernels: x = chunks of one plane, y = (sample groups) x C.
+// Every block should see >= ~4096 elements: big planes get one block (or several) per
+// (n, c) plane, the 64..512-element planes of the last stages several samples per block.
+inline dim3 plane_grid(int N, int C, int S) {
   int gx = cdiv(S >> 2 ? S >> 2 : S, 256 * 4);
   if (gx < 1) gx = 1;
   if (gx > 64) gx = 64;
-  int gy = planes;
-  const int cap = 65535;
-  if (gy > cap) gy = cap;
+  int nsg = N;
+  if (S < 4096) {
+    const long per = 4096 / S;            // samples per block
+    nsg = cdiv(N, per);
+  }
+  if ((long)nsg * C > 65535) nsg = 65535 / C;
+  if (nsg < 1) nsg = 1;
   // keep total blocks bounded for very large tensors
-  while ((long)gx * gy > 262144 && gx > 1) gx >>= 1;
-  return dim3(gx, gy);
+  while ((long)gx * nsg * C > 262144 && gx > 1) gx >>= 1;
+  return dim3(gx, nsg * C);
+}
+
+// sample groups of the backward reduce (one fp64 partial pair per (channel, group))
+inline int reduce_groups(int N, int S) {
+  if (S >= 4096) return N;
+  int g = cdiv(N, 4096 / S);
+  return g < 1 ? 1 : g;
 }
 
 }  // namespace
@@ -301,7 +317,7 @@ extern "C" int coclr_bn_act_apply(const float* y, const float* scale, const floa
   if (N <= 0 || C <= 0 || S <= 0) return COCLR_EINVAL;
   const bool vec = (S % 4 == 0) && (y_nstride % 4 == 0) && (z_nstride % 4 == 0) &&
                    (!residual || res_nstride % 4 == 0);
-  dim3 grid = plane_grid(N * C, (int)S);
+  dim3 grid = plane_grid(N, C, (int)S);
   if (vec)
     hipLaunchKernelGGL(bn_act_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, scale,
                        shift, residual, z, N, C, (int)S, (long)y_nstride, (long)z_nstride,
@@ -332,8 +348,9 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
   const bool vec = (S % 4 == 0) && (dz_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
                    (dy_nstride % 4 == 0) && (!z || z_nstride % 4 == 0) &&
                    (!dres || dres_nstride % 4 == 0);
-  // pass 1: per (channel, sample) partial sums of g and g*xhat
-  dim3 rgrid(C, N);
+  // pass 1: per (channel, sample group) partial sums of g and g*xhat
+  const int groups = reduce_groups(N, (int)S);
+  dim3 rgrid(C, groups);
   if (vec)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, stream, dz, y, z, scale,
                        shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride,
@@ -345,16 +362,16 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
   COCLR_LAUNCH_CHECK();
   // pass 2: fold the partials, coefficients, dy (+ dres), dgamma / dbeta
   const double count = (double)N * (double)S;
-  dim3 grid = plane_grid(N * C, (int)S);
+  dim3 grid = plane_grid(N, C, (int)S);
   if (vec)
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, grid, dim3(256), 0, stream, dz, y, z, scale,
-                       shift, mean, invstd, sums_ws, N, count, training, dgamma, dbeta, dy, dres, N,
-                       C, (int)S, (long)dz_nstride, (long)y_nstride, (long)dy_nstride,
+                       shift, mean, invstd, sums_ws, groups, count, training, dgamma, dbeta, dy, dres,
+                       N, C, (int)S, (long)dz_nstride, (long)y_nstride, (long)dy_nstride,
                        (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
   else
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, grid, dim3(256), 0, stream, dz, y, z, scale,
-                       shift, mean, invstd, sums_ws, N, count, training, dgamma, dbeta, dy, dres, N,
-                       C, (int)S, (long)dz_nstride, (long)y_nstride, (long)dy_nstride,
+                       shift, mean, invstd, sums_ws, groups, count, training, dgamma, dbeta, dy, dres,
+                       N, C, (int)S, (long)dz_nstride, (long)y_nstride, (long)dy_nstride,
                        (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
   COCLR_LAUNCH_CHECK();
   return 0;
