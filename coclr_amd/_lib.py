@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -65,6 +65,10 @@ _SIGNATURES = {
     "coclr_relu_fwd": [vp, vp, i64, vp],
     "coclr_relu_bwd": [vp, vp, vp, i64, vp],
     "coclr_colsum": [vp, vp, i32, i32, vp],
+    "coclr_sigmoid_fwd": [vp, vp, i64, vp],
+    "coclr_sigmoid_bwd": [vp, vp, vp, i64, vp],
+    "coclr_plane_scale": [vp, vp, vp, vp, i32, i32, i64, i64, i64, i32, vp],
+    "coclr_plane_dot": [vp, vp, vp, i32, i32, i64, i64, i64, vp],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

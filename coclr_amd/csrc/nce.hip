@@ -448,6 +448,93 @@ extern "C" int coclr_gather_rows(const float* in, const int64_t* idx, float* out
   return 0;
 }
 
+// ---- S3D-G self gating (backbone/s3dg.py:68-78): out = x * sigmoid(fc(mean(x))) ----------
+namespace {
+
+// w = sigmoid(s); ds = dw * w * (1 - w) for the backward
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ s, float* __restrict__ w, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    w[e] = 1.f / (1.f + expf(-s[e]));
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ w,
+                                   float* __restrict__ ds, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    ds[e] = dw[e] * w[e] * (1.f - w[e]);
+}
+
+// out[n][c][:] (+)= a[n][c][:] * g[n*C+c] + b[n*C+c]   (one wave per plane, 16 B lanes)
+__global__ void __launch_bounds__(256)
+plane_scale_kernel(const float* __restrict__ a, const float* __restrict__ g,
+                   const float* __restrict__ b, float* out, int planes, int C, int S,
+                   long a_nstride, long out_nstride, int accumulate) {
+  const int pl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pl >= planes) return;
+  const int n = pl / C, c = pl - n * C;
+  const float gv = g[pl], bv = b ? b[pl] : 0.f;
+  const float* ap = a + (long)n * a_nstride + (long)c * S;
+  float* op = out + (long)n * out_nstride + (long)c * S;
+  for (int i = lane; i < S; i += 64) {
+    const float v = fmaf(ap[i], gv, bv);
+    op[i] = accumulate ? op[i] + v : v;
+  }
+}
+
+// out[n*C+c] = sum_s a[n][c][s] * b[n][c][s]   (one wave per plane)
+__global__ void __launch_bounds__(256)
+plane_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                 int planes, int C, int S, long a_nstride, long b_nstride) {
+  const int pl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pl >= planes) return;
+  const int n = pl / C, c = pl - n * C;
+  const float* ap = a + (long)n * a_nstride + (long)c * S;
+  const float* bp = b + (long)n * b_nstride + (long)c * S;
+  float acc = 0.f;
+  for (int i = lane; i < S; i += 64) acc = fmaf(ap[i], bp[i], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) out[pl] = acc;
+}
+
+}  // namespace
+
+extern "C" int coclr_sigmoid_fwd(const float* s, float* w, int64_t n, void* stream) {
+  if (n <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, s, w,
+                     (long)n);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_sigmoid_bwd(const float* dw, const float* w, float* ds, int64_t n,
+                                 void* stream) {
+  if (n <= 0) return COCLR_EINVAL;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dw, w,
+                     ds, (long)n);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_plane_scale(const float* a, const float* gain, const float* bias, float* out,
+                                 int N, int C, int64_t S, int64_t a_nstride, int64_t out_nstride,
+                                 int accumulate, void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return COCLR_EINVAL;
+  const int planes = N * C;
+  hipLaunchKernelGGL(plane_scale_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream,
+                     a, gain, bias, out, planes, C, (int)S, (long)a_nstride, (long)out_nstride,
+                     accumulate);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_plane_dot(const float* a, const float* b, float* out, int N, int C, int64_t S,
+                               int64_t a_nstride, int64_t b_nstride, void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return COCLR_EINVAL;
+  const int planes = N * C;
+  hipLaunchKernelGGL(plane_dot_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, a,
+                     b, out, planes, C, (int)S, (long)a_nstride, (long)b_nstride);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int coclr_relu_fwd(const float* x, float* y, int64_t n, void* stream) {
   if (n <= 0) return COCLR_EINVAL;
   hipLaunchKernelGGL(relu_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, x, y,

@@ -528,28 +528,42 @@ def subsample(run, x, stride):
 # ---------------------------------------------------------------------------------
 
 def self_gating(run, x, fc, out=None):
+    """SelfGating.forward (backbone/s3dg.py:73-78): out = x * sigmoid(fc(mean_{T,H,W} x))."""
     xv = x.view()
-    a = xv.mean(dim=(2, 3, 4))
-    wgt = torch.sigmoid(torch.addmm(fc.bias, a, fc.weight.t()))
+    N, C_ = xv.shape[0], xv.shape[1]
+    S = xv.shape[2] * xv.shape[3] * xv.shape[4]
+    if not xv.is_contiguous():
+        raise NotImplementedError("coclr_amd: self gating expects a dense input")
+    a5 = run.empty(N, C_, 1, 1, 1)
+    ops.global_avgpool_fwd(xv, a5)
+    a = a5.view(N, C_)
+    s_ = run.empty(N, C_)
+    W_ = fc.weight                                 # [C][C], s = a @ W^T + b
+    ops.gemm(a, C_, 1, W_, 1, C_, s_, C_, fc.bias, N, C_, C_)
+    wgt = run.empty(N, C_)
+    ops.sigmoid_fwd(s_, wgt)
     if out is None:
         out = Val(torch.empty_like(xv))
-    torch.mul(xv, wgt[:, :, None, None, None], out=out.view())
+    ops.plane_scale(xv, wgt, None, out.view())
     if run.save:
         def backward():
             dout = run.grad_of(out)
-            dwgt = (dout * xv).sum(dim=(2, 3, 4))
-            ds = dwgt * wgt * (1 - wgt)
+            dwgt = run.empty(N, C_)
+            ops.plane_dot(dout, xv, dwgt)
+            ds = run.empty(N, C_)
+            ops.sigmoid_bwd(dwgt, wgt, ds)
             if fc.weight.requires_grad:
-                run.add_param_grad(fc.weight, ds.t().mm(a))
-                run.add_param_grad(fc.bias, ds.sum(0))
+                dW = torch.empty_like(W_)          # dW[o][i] = sum_n ds[n][o] a[n][i]
+                ops.gemm(ds, 1, C_, a, C_, 1, dW, C_, None, C_, C_, N)
+                db = run.empty(C_)
+                ops.colsum(ds, db)
+                run.add_param_grad(fc.weight, dW)
+                run.add_param_grad(fc.bias, db)
             if run.needs_grad(x):
-                S = xv.shape[2] * xv.shape[3] * xv.shape[4]
-                dx = dout * wgt[:, :, None, None, None] + (ds.mm(fc.weight) / S)[:, :, None, None, None]
+                back = run.empty(N, C_)            # (ds @ W) / S, added to every element of a plane
+                ops.gemm(ds, C_, 1, W_, C_, 1, back, C_, None, N, C_, C_, alpha=1.0 / S)
                 g, acc = run.grad_target(x)
-                if acc:
-                    g.add_(dx)
-                else:
-                    g.copy_(dx)
+                ops.plane_scale(dout, wgt, back, g, accumulate=acc)
         run.record(backward)
     return out
 

@@ -408,3 +408,28 @@ def relu_bwd(dy, y, dx):
 def colsum(x, out):
     rows, cols = x.shape
     _lib.check(_L().coclr_colsum(_p(x), _p(out), rows, cols, _stream()), "colsum")
+
+
+# ---- S3D-G self gating ---------------------------------------------------------------
+
+def sigmoid_fwd(s_, w):
+    _lib.check(_L().coclr_sigmoid_fwd(_p(s_), _p(w), s_.numel(), _stream()), "sigmoid_fwd")
+
+
+def sigmoid_bwd(dw, w, ds):
+    _lib.check(_L().coclr_sigmoid_bwd(_p(dw), _p(w), _p(ds), w.numel(), _stream()), "sigmoid_bwd")
+
+
+def plane_scale(a, gain, bias, out, accumulate=False):
+    """out[n][c][:] (+)= a[n][c][:] * gain[n][c] + bias[n][c]; a / out may be channel slices."""
+    N, C_, T, H, W = a.shape
+    _lib.check(_L().coclr_plane_scale(_p(a), _p(gain), _p(bias), _p(out), N, C_, T * H * W,
+                                      _chk5(a, "a"), _chk5(out, "out"), int(accumulate), _stream()),
+               "plane_scale")
+
+
+def plane_dot(a, b, out):
+    """out[n][c] = <a[n][c], b[n][c]> over (T, H, W)."""
+    N, C_, T, H, W = a.shape
+    _lib.check(_L().coclr_plane_dot(_p(a), _p(b), _p(out), N, C_, T * H * W, _chk5(a, "a"),
+                                    _chk5(b, "b"), _stream()), "plane_dot")

@@ -219,6 +219,19 @@ int coclr_relu_fwd(const float* x, float* y, int64_t n, void* stream);
 int coclr_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int coclr_colsum(const float* x, float* out, int rows, int cols, void* stream);
 
+/* S3D-G self gating (backbone/s3dg.py:68-78): out = x * sigmoid(fc(mean_{T,H,W} x)).
+ * The mean is coclr_global_avgpool_fwd, fc is coclr_gemm; these supply the rest:
+ * w = sigmoid(s) and ds = dw*w*(1-w); out[n][c][:] (+)= a[n][c][:]*gain[n*C+c] + bias[n*C+c]
+ * (forward scaling, and dx = dout*w + (ds.W)/S in the backward); out[n*C+c] = <a, b> per
+ * (n, c) plane (dw of the backward). */
+int coclr_sigmoid_fwd(const float* s, float* w, int64_t n, void* stream);
+int coclr_sigmoid_bwd(const float* dw, const float* w, float* ds, int64_t n, void* stream);
+int coclr_plane_scale(const float* a, const float* gain, const float* bias, float* out, int N, int C,
+                      int64_t S, int64_t a_nstride, int64_t out_nstride, int accumulate,
+                      void* stream);
+int coclr_plane_dot(const float* a, const float* b, float* out, int N, int C, int64_t S,
+                    int64_t a_nstride, int64_t b_nstride, void* stream);
+
 /* Library/ABI version, bumped when a signature changes. */
 int coclr_abi_version(void);
 

@@ -297,6 +297,28 @@ def colsum(x, out):
     out.copy_(x.sum(0))
 
 
+def sigmoid_fwd(s_, w):
+    w.copy_(torch.sigmoid(s_))
+
+
+def sigmoid_bwd(dw, w, ds):
+    ds.copy_(dw * w * (1 - w))
+
+
+def plane_scale(a, gain, bias, out, accumulate=False):
+    v = a * gain[:, :, None, None, None]
+    if bias is not None:
+        v = v + bias[:, :, None, None, None]
+    if accumulate:
+        out.add_(v)
+    else:
+        out.copy_(v)
+
+
+def plane_dot(a, b, out):
+    out.copy_((a * b).sum((2, 3, 4)))
+
+
 _NAMES = [n for n, v in list(globals().items())
           if callable(v) and not n.startswith("_") and hasattr(ops, n) and n not in ("F",)]
 

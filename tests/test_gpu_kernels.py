@@ -421,3 +421,37 @@ def test_momentum_enqueue_mask_gather():
     cs = torch.empty(60, device="cuda")
     ops.colsum(dev(xr), cs)
     close(cs, xr.sum(0), what="colsum")
+
+
+def test_self_gating_kernels():
+    """sigmoid / per-plane scale / per-plane dot of S3D-G's SelfGating (backbone/s3dg.py:68-78),
+    with channel-slice operands and the accumulate form used by the backward."""
+    from coclr_amd import ops
+    torch.manual_seed(12)
+    N, Cc, dims = 3, 10, (2, 5, 7)
+    wide = torch.randn(N, Cc + 4, *dims)
+    a = wide[:, 2:2 + Cc]
+    gain, bias = torch.randn(N, Cc), torch.randn(N, Cc)
+    wd = dev(wide)
+    out = torch.zeros(N, Cc + 6, *dims, device="cuda")
+    ops.plane_scale(wd[:, 2:2 + Cc], dev(gain), None, out[:, 3:3 + Cc])
+    close(out[:, 3:3 + Cc], a * gain[:, :, None, None, None], what="plane_scale")
+    assert out[:, :3].abs().max().item() == 0 and out[:, 3 + Cc:].abs().max().item() == 0
+    base = torch.randn(N, Cc, *dims)
+    acc = dev(base)
+    ops.plane_scale(wd[:, 2:2 + Cc], dev(gain), dev(bias), acc, accumulate=True)
+    close(acc, base + a * gain[:, :, None, None, None] + bias[:, :, None, None, None],
+          what="plane_scale accumulate")
+    b = torch.randn(N, Cc, *dims)
+    dots = torch.empty(N, Cc, device="cuda")
+    ops.plane_dot(wd[:, 2:2 + Cc], dev(b), dots)
+    close(dots, (a * b).sum((2, 3, 4)), what="plane_dot")
+    s_ = torch.randn(N, Cc) * 3
+    w = torch.empty(N, Cc, device="cuda")
+    ops.sigmoid_fwd(dev(s_), w)
+    close(w, torch.sigmoid(s_), what="sigmoid")
+    dw = torch.randn(N, Cc)
+    ds = torch.empty(N, Cc, device="cuda")
+    ops.sigmoid_bwd(dev(dw), w, ds)
+    sg = torch.sigmoid(s_)
+    close(ds, dw * sg * (1 - sg), what="sigmoid backward")
