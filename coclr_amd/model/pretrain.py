@@ -36,6 +36,35 @@ def _world():
     return 1, 0
 
 
+def route_plan(perm, B, world, rank):
+    """Routing of the shuffle-BN exchange for one rank.  `perm` is the global permutation
+    (list of B*world clip ids, clip g lives on rank g // B at local index g % B); rank r encodes
+    the clips perm[r*B:(r+1)*B] in that order.  Returns
+      send_order  local indices of this rank's clips laid out by destination rank (for each
+                  destination, in the order that destination wants them),
+      in_splits   clips sent to each rank,  out_splits  clips received from each rank,
+      pos         pos[i] = row of the receive buffer (rows grouped by source rank, all_to_all
+                  order) that holds the i-th clip this rank has to encode."""
+    send_order, in_splits = [], []
+    for r in range(world):
+        mine = [g % B for g in perm[r * B:(r + 1) * B] if g // B == rank]
+        send_order += mine
+        in_splits.append(len(mine))
+    wanted = perm[rank * B:(rank + 1) * B]
+    out_splits = [sum(1 for g in wanted if g // B == src) for src in range(world)]
+    offs, acc = [], 0
+    for c in out_splits:
+        offs.append(acc)
+        acc += c
+    seen = [0] * world
+    pos = []
+    for g in wanted:
+        src = g // B
+        pos.append(offs[src] + seen[src])
+        seen[src] += 1
+    return send_order, in_splits, out_splits, pos
+
+
 @torch.no_grad()
 def concat_all_gather(tensor):
     """All-gather along dim 0 (no gradient), one RCCL all_gather_into_tensor
@@ -477,26 +506,7 @@ class InfoNCE(nn.Module):
         B = x2.shape[0]
         perm = torch.randperm(B * world)                  # same RNG use as the reference (:112)
         dist.broadcast(perm, src=0, group=self._host_group())
-        p = perm.tolist()
-        # what I send: for destination r, my clips it wants, in the order it wants them
-        send_order, in_splits = [], []
-        for r in range(world):
-            mine = [g % B for g in p[r * B:(r + 1) * B] if g // B == rank]
-            send_order += mine
-            in_splits.append(len(mine))
-        # what I receive: rows grouped by source rank, each group in my wanted order
-        wanted = p[rank * B:(rank + 1) * B]
-        out_splits = [sum(1 for g in wanted if g // B == src) for src in range(world)]
-        offs, acc = [], 0
-        for c in out_splits:
-            offs.append(acc)
-            acc += c
-        seen = [0] * world
-        pos = []
-        for g in wanted:
-            src = g // B
-            pos.append(offs[src] + seen[src])
-            seen[src] += 1
+        send_order, in_splits, out_splits, pos = route_plan(perm.tolist(), B, world, rank)
         dev = x2.device
         order_t = torch.tensor(send_order, dtype=torch.int64).to(dev, non_blocking=True)
         sendbuf = torch.empty((B,) + tuple(x2.shape[1:]), dtype=x2.dtype, device=dev)

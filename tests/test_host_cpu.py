@@ -186,3 +186,32 @@ def test_state_dict_is_reference_compatible():
     product.CoCLR('s3d', 128, 64, 0.999, 0.07, 5, True)
     with pytest.raises(NotImplementedError):
         product.InfoNCE('resnet18')
+
+
+@pytest.mark.parametrize("world,B", [(2, 3), (4, 8), (8, 32)])
+def test_routed_shuffle_plan_delivers_every_clip_once(world, B):
+    """The shuffle-BN exchange as an all-to-all (model.pretrain.route_plan): simulate every rank's
+    send buffer and the all_to_all_single semantics, and check that each rank ends up with exactly
+    the clips perm[r*B:(r+1)*B] in that order -- what the reference obtains by all-gathering
+    everything and indexing (model/pretrain.py:106-124)."""
+    from coclr_amd.model.pretrain import route_plan
+    g = torch.Generator().manual_seed(world * 100 + B)
+    for trial in range(5):
+        perm = torch.randperm(world * B, generator=g).tolist()
+        plans = [route_plan(perm, B, world, r) for r in range(world)]
+        # sender side: rank s lays its clips out by destination
+        sendbufs = [[s * B + li for li in plans[s][0]] for s in range(world)]     # global clip ids
+        for s in range(world):
+            assert sorted(plans[s][0]) == list(range(B))            # every local clip leaves once
+            assert sum(plans[s][1]) == B
+        for r in range(world):
+            send_order, in_splits, out_splits, pos = plans[r]
+            # all_to_all_single: chunk (src -> r) is the r-th chunk of src's send buffer
+            recv = []
+            for src in range(world):
+                off = sum(plans[src][1][:r])
+                chunk = sendbufs[src][off:off + plans[src][1][r]]
+                assert len(chunk) == out_splits[src]                 # split sizes agree pairwise
+                recv += chunk
+            assert len(recv) == B
+            assert [recv[p] for p in pos] == perm[r * B:(r + 1) * B]
