@@ -436,6 +436,141 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
 }
 
 // ------------------------------------------------------------------------------------
+// Pointwise (1x1x1) weight gradient: dW[co][ci] = sum_p dY[co][p] * X[ci][p] is a plain GEMM
+// whose two operands are both runs of contiguous positions.  The generic v2 kernel moves them
+// with 4-byte DMA (256 instructions per 128x128x64 box: the loader waves, not the matrix
+// pipes, set its pace -- 38 TFLOP/s).  Here
+//   * both tiles are [row][64 positions] with NO padding, filled by 16-byte LDS-DMA
+//     (64 instructions per box);
+//   * bank conflicts are avoided by an XOR swizzle of the 16-byte chunk index with the row
+//     (applied on the SOURCE side of the DMA, whose LDS destination is fixed per lane), and the
+//     operands are fetched with ds_read_b128: lane (row, half) gets positions 8j+4*half..+3 and
+//     feeds them to four consecutive MFMA steps (step t pairs positions 8j+t and 8j+4+t for
+//     both operands), i.e. one LDS read per operand block per 4 steps.
+// Requirements (checked on the host): stride 1, plane size a multiple of 64, 16-byte aligned
+// tensors and strides.
+template <int MB, int NB>
+__global__ void __launch_bounds__(512)
+conv_wgrad_pw_kernel(const Wgrad2Args a) {
+  constexpr int BMt = 64 * MB, BCt = 64 * NB;
+  constexpr int ROW = 64;                               // floats per row = positions per box
+  constexpr int stage_floats = (BMt + BCt) * ROW;
+  constexpr int APIECES = BMt / 4, BPIECES = BCt / 4;  // 1 KiB pieces (4 rows each)
+
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int ci0 = blockIdx.y * BCt, co0 = blockIdx.z * BMt;
+  const int nbox = (a.ntiles - split + a.S - 1) / a.S;
+  const int S = a.Wi;                                   // flattened plane size
+  const int boxes_per_sample = S >> 6;
+
+  if (wave >= 4) {
+    // =============================== loader waves ===============================
+    const int lw = wave - 4;
+    const int r = lane >> 4, q = lane & 15;             // row inside a piece, LDS chunk slot
+    unsigned voff_a[4], voff_b[4];                      // by (piece & 3): source chunk = q ^ (row & 15)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = q ^ ((k * 4 + r) & 15);
+      voff_a[k] = (unsigned)(((long)r * a.dy_cstride + c4 * 4) * 4);
+      voff_b[k] = (unsigned)(((long)r * a.x_cstride + c4 * 4) * 4);
+    }
+    for (int b = 0; b < nbox; ++b) {
+      const int tile = split + b * a.S;
+      const int n = tile / boxes_per_sample;
+      const int p0 = (tile - n * boxes_per_sample) << 6;
+      float* As = smem + (b & 1) * stage_floats;
+      float* Bs = As + BMt * ROW;
+      const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.dy + (long)n * a.dy_nstride + p0), 0, 0x80000000u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.x + (long)n * a.x_nstride + p0), 0, 0x80000000u, 0x00020000);
+      for (int p = lw; p < APIECES; p += 4) {
+        const int row = co0 + p * 4;
+        const unsigned vo = row + r < a.Cout ? voff_a[p & 3] : W2_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(As + p * 256), 16, vo,
+                                                 (unsigned)row * (unsigned)a.dy_cstride * 4u, 0, 0);
+      }
+      for (int p = lw; p < BPIECES; p += 4) {
+        const int row = ci0 + p * 4;
+        const unsigned vo = row + r < a.Cin ? voff_b[p & 3] : W2_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(Bs + p * 256), 16, vo,
+                                                 (unsigned)row * (unsigned)a.x_cstride * 4u, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+      __syncthreads();                      // barrier b
+    }
+    return;
+  }
+
+  // ================================ matrix waves ================================
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  int arow[MB], brow[NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) arow[mb] = (wm * MB + mb) * 32 + l31;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) brow[nb] = (wn * NB + nb) * 32 + l31;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  for (int b = 0; b < nbox; ++b) {
+    const float* As = smem + (b & 1) * stage_floats;
+    const float* Bs = As + BMt * ROW;
+    __syncthreads();   // barrier b
+    f32x4 av[2][MB], bv[2][NB];
+    auto fetch = [&](int j, f32x4 (&A)[MB], f32x4 (&B)[NB]) {
+      const int c4 = 2 * j + half;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        A[mb] = *reinterpret_cast<const f32x4*>(As + arow[mb] * ROW + ((c4 ^ (arow[mb] & 15)) << 2));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        B[nb] = *reinterpret_cast<const f32x4*>(Bs + brow[nb] * ROW + ((c4 ^ (brow[nb] & 15)) << 2));
+    };
+    fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j + 1 < 8) fetch(j + 1, av[(j + 1) & 1], bv[(j + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][mb][t], bv[j & 1][nb][t],
+                                                               acc[mb][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  float* out = a.part + (long)split * a.Cout * a.J;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co0 + (wm * MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (co < a.Cout) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int ci = ci0 + (wn * NB + nb) * 32 + l31;
+          if (ci < a.Cin) out[(long)co * a.J + ci] = acc[mb][nb][i];
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Stem weight gradient: (1,KH,KW) stencil over CIN = 3 input channels (s3dg.py:145 conv1 and
 // the slices of resnet_2d3d.py:138).  J = CIN*KH*KW = 147 columns would half-fill a second
 // 128-column tile of the (ci,tap)-lane kernel and its window reads collide in LDS.  Here:
@@ -667,6 +802,7 @@ struct WPlan {
   int variant, BJ, S, jtiles, mtiles, planeP, pch, nci_max;
   // second-generation kernel
   int v2;            // 0: not applicable, else variant id
+  int pw;            // pointwise: 16-byte-DMA GEMM kernel applicable
   ConvPlan p2;
   int S2, planeP2, mt2, ct2;
   size_t lds2;
@@ -675,6 +811,7 @@ struct WPlan {
 // tile of the v2 kernel for a stencil: returns variant id or 0
 // stem: (1,7,7) over 3 channels -> conv_wgrad_stem_kernel; fills the v2 plan fields
 int pick_stem(const coclr_conv_desc* d, WPlan* w) {
+  w->pw = 0;
   if (!(d->kt == 1 && d->kh == 7 && d->kw == 7 && d->Cin == 3)) return 0;
   ConvPlan& p = w->p2;
   conv_normalise(d, &p);
@@ -705,6 +842,7 @@ int pick_stem(const coclr_conv_desc* d, WPlan* w) {
 int pick_v2(const coclr_conv_desc* d, WPlan* w) {
   const int kt = d->kt, kh = d->kh, kw = d->kw;
   int MB = 1, NB = 1, id = 0;
+  w->pw = 0;
   if (kt == 1 && kh == 3 && kw == 3) id = 1;
   else if (kt == 3 && kh == 1 && kw == 1) id = 2;
   else if (kt == 7 && kh == 1 && kw == 1) id = 3;
@@ -719,6 +857,12 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
   ConvPlan& p = w->p2;
   conv_normalise(d, &p);
   conv_pick_box(&p, 6, kt, kh, kw);
+  if ((id == 4 || id == 5) && p.Ti == 1 && p.Hi == 1 && p.lTW == 6 && p.lTN == 0 &&
+      (p.Wi % 64) == 0 && (d->x_nstride % 4) == 0 && (d->y_nstride % 4) == 0) {
+    // contiguous 64-position boxes, everything 16-byte aligned: the 16-byte-DMA GEMM kernel
+    // (pointer alignment is checked at launch)
+    w->pw = 1;
+  }
   if (p.lTW < 1) return 0;
   const int pch = cdiv(p.plane, 64);
   const int maxpch = id == 1 ? 3 : (id == 3 ? 4 : 2);
@@ -846,6 +990,32 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
     a.inv_ww = 1.0f / (float)p.WW;
     a.ntiles = p.ntiles; a.S = w.S2;
     const int pch = cdiv(p.plane, 64);
+    const bool pw = w.pw && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0;
+    if (pw) {
+      const bool big = w.v2 == 4;
+      const size_t lds = (size_t)2 * (big ? 256 : 128) * 64 * sizeof(float);
+      if (big) {
+        auto kern = conv_wgrad_pw_kernel<2, 2>;
+        static bool attr_done = false;
+        if (!attr_done) {
+          COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(512), lds, stream, a);
+      } else {
+        auto kern = conv_wgrad_pw_kernel<1, 1>;
+        static bool attr_done = false;
+        if (!attr_done) {
+          COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(512), lds, stream, a);
+      }
+      COCLR_LAUNCH_CHECK();
+      rc = 0;
+    } else
     switch (w.v2) {
       case 1: rc = pch <= 2 ? launch_wgrad2<1, 3, 3, 1, 1, 2>(a, w, stream)
                             : launch_wgrad2<1, 3, 3, 1, 1, 3>(a, w, stream); break;
