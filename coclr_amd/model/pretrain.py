@@ -427,7 +427,7 @@ class InfoNCE(nn.Module):
     # -- hipGraph replay of the gradient-free encoders --------------------------------------
     def _encode_graphed(self, encoder, src, n_index, pre=None):
         """encoder(src[n_index]) -> L2-normalised keys, without autograd, replayed from a
-        captured hipGraph after two eager warm-up calls.
+        captured hipGraph after one eager warm-up call.
 
         A no-grad encoder pass is ~330 kernel launches whose arguments do not change from step
         to step (weights, BN buffers and packed operands live at fixed addresses): capturing it
@@ -451,7 +451,7 @@ class InfoNCE(nn.Module):
         ent = store.get(id(encoder))
         if ent is None or ent["sig"] != sig:
             ent = store[id(encoder)] = {"sig": sig, "calls": 0}
-        if ent["calls"] < 2:                       # warm-up: kernels' one-time attribute calls etc.
+        if ent["calls"] < 1:                       # first call eager: one-time attribute calls etc.
             ent["calls"] += 1
             if pre is not None:
                 pre()

@@ -164,7 +164,7 @@ def test_select_backbone_contract():
 
 
 def test_graph_replay_matches_eager():
-    """From its third call on, a gradient-free encoder pass is replayed from a captured hipGraph
+    """From its second call on, a gradient-free encoder pass is replayed from a captured hipGraph
     (model.pretrain._encode_graphed).  The same key encoder driven five times through the
     graph path and through the eager path (identical copies, identical inputs, momentum update
     as the captured prologue): keys, momentum-updated weights and BatchNorm running statistics
