@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
         "N", "Cin", "Cout", "Ti", "Hi", "Wi", "To", "Ho", "Wo", "kt", "kh", "kw",
         "st", "sh", "sw", "pt", "ph", "pw", "dt", "dh", "dw")] + [
         ("x_nstride", i64), ("y_nstride", i64)] + [(n, i32) for n in (
-        "ys_t", "ys_h", "ys_w", "yo_t", "yo_h", "yo_w", "yT", "yH", "yW", "Nx")]
+        "ys_t", "ys_h", "ys_w", "yo_t", "yo_h", "yo_w", "yT", "yH", "yW", "Nx", "algo")]
 
 
 class PoolDesc(C.Structure):

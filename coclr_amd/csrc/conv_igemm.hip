@@ -369,6 +369,333 @@ conv_igemm_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// Temporal (3,1,1) stride-1 convolutions through Winograd F(2,3) along T.
+//
+// A pair of output frames (2p, 2p+1) needs input frames d0..d3 = 2p-1 .. 2p+2 and FOUR channel
+// contractions instead of six:
+//     m0 = G0 (d0 - d2)   m1 = G1 (d1 + d2)   m2 = G2 (d2 - d1)   m3 = G3 (d1 - d3)
+//     y[2p] = m0 + m1 + m2          y[2p+1] = m1 - m2 - m3
+// with G0 = w0, G1 = (w0+w1+w2)/2, G2 = (w0-w1+w2)/2, G3 = w2 ([Cout][Cin] matrices, prepared
+// by pack_weights_kernel as a 4-"tap" operand).  Everything stays fp32; measured against float64
+// the result is as accurate as the direct fp32 convolution (tools/winograd_probe.py: 5e-7).
+//
+// Seen from the implicit-GEMM kernel above this is a (4,1,1) stencil with temporal stride 2
+// over "pair positions": same box / window / LDS-DMA staging / weight tile; what differs is that
+// the B operand of virtual tap i is a difference or sum of two window rows (one VALU op), that a
+// wave keeps four accumulators per 32x32 block, and that the epilogue emits two frames.
+// 1.5x fewer MFMAs for the (3,1,1) layers (27 % of the S3D conv FLOPs), forward and dgrad.
+template <int CC, int BM, int BNP, int PCH, bool XV4>
+__global__ void __launch_bounds__(256)
+conv_wino_t_kernel(const ConvArgs a) {
+  constexpr int TAPS = 4;
+  constexpr int WM = 2, WN = 2;
+  constexpr int MF = BM / (WM * 32), NF = BNP / (WN * 32);
+  constexpr int RPP = 256 / BM;
+  constexpr int WPIECES = TAPS * CC / RPP;
+  static_assert(CC % RPP == 0 && CC % 4 == 0, "chunk shape");
+  constexpr int W_FLOATS = TAPS * CC * BM;
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeS = a.planeS;
+  const int stage_floats = W_FLOATS + CC * planeS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int bid = blockIdx.x;
+  const int mt = bid % a.mtiles;
+  const int ntile = bid / a.mtiles;
+  int r = ntile;
+  const int bw_ = r % a.nbw; r /= a.nbw;
+  const int bh_ = r % a.nbh; r /= a.nbh;
+  const int bt_ = r % a.nbt; r /= a.nbt;
+  const int n0 = r << a.lTN;
+  const int ow0 = bw_ << a.lTW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;   // ot0: PAIR index
+  const int cout0 = mt * BM;
+  const int vt0 = ot0 * 2 - 1, vh0 = oh0, vw0 = ow0;                      // window origin
+  const int plane = a.plane;
+
+  const float* xbase = a.x + (long)n0 * a.x_nstride;
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, BUF_RANGE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
+  float* ybase = a.y + (long)n0 * a.y_nstride;
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, BUF_RANGE, 0x00020000);
+
+  unsigned goff[PCH];
+  {
+    const int hw = a.WH * a.WW;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int e = j * 64 + lane;
+      unsigned off = OOB;
+      if (e < plane) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
+        const int wh = fdiv(q, a.inv_ww);
+        const int ww = q - wh * a.WW;
+        const int n = n0 + wn_;
+        const int it = vt0 + wt, ih = vh0 + wh, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && ih < a.Hi && iw < a.Wi)
+          off = (unsigned)(((long)wn_ * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4);
+      }
+      goff[j] = off;
+    }
+  }
+  const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
+
+  // XV4: the window of a temporal stencil has no halo along the flattened (H,W) axis, so with
+  // everything 16-byte aligned it can be staged by 16-byte DMA.  The LDS image [c][plane] is
+  // then filled in 1 KiB pieces that run across channel boundaries: piece j, lane L holds
+  // floats 256j + 4L .. +3.  Wave w owns pieces w, w+4, ...
+  constexpr int PV = (CC * PCH * 64 / 256 + 3) / 4;      // pieces per wave (upper bound)
+  unsigned xvoff[PV];
+  int xvc[PV];
+  if (XV4) {
+#pragma unroll
+    for (int jj = 0; jj < PV; ++jj) {
+      const int flat = (wave + 4 * jj) * 256 + lane * 4;
+      const int c = flat / plane, e = flat - c * plane;
+      unsigned off = OOB;
+      if (c < CC) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        const int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_ww);              // WH == 1 here
+        const int ww = q - wt * a.WW;
+        const int n = n0 + wn_, it = vt0 + wt, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && iw < a.Wi)
+          off = (unsigned)(((long)wn_ * a.x_nstride + (long)it * a.Wi + iw + (long)c * a.x_cstride) * 4);
+      }
+      xvoff[jj] = off;
+      xvc[jj] = c;
+    }
+  }
+
+  // pair position of this lane: window offset of its frame d0 (d1..d3 follow at +WH*WW each)
+  int lanebase[NF];
+  const int fstride = a.WH * a.WW;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BNP / WN) + nf * 32 + l31;
+    const int tw = p & ((1 << a.lTW) - 1);
+    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    lanebase[nf] = W_FLOATS + tn * a.plane1 + ((tt * 2) * a.WH + th) * a.WW + tw + half * planeS;
+  }
+  const int abase = half * BM + wm * (BM / WM) + l31;
+
+  f32x16 acc[MF][NF][4];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mf][nf][t][i] = 0.f;
+
+  auto stage = [&](int cin0, float* sbase) {
+    for (int p = wave; p < WPIECES; p += 4) {
+      const int row0 = p * RPP;
+      const int tap = row0 / CC, c0 = row0 % CC;
+      const unsigned soff = (unsigned)((((long)tap * a.CinP + cin0 + c0) * a.CoutP + cout0) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sbase + p * 256), 16, wvoff, soff, 0, 0);
+    }
+    float* xs = sbase + W_FLOATS;
+    if (XV4) {
+      const unsigned soff = (unsigned)cin0 * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+      for (int jj = 0; jj < PV; ++jj) {
+        const int j = wave + 4 * jj;
+        if (j * 256 < CC * plane && xvc[jj] < CC) {   // exec-masked: lanes past the image write nothing
+          const unsigned vo = cin0 + xvc[jj] < a.Cin ? xvoff[jj] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + j * 256), 16, vo, soff, 0, 0);
+        }
+      }
+    } else
+#pragma unroll
+    for (int ci = 0; ci < CC / 4; ++ci) {
+      const int c = ci * 4 + wave;
+      const int cin = cin0 + c;
+      if (cin < a.Cin) {
+        const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
+                                                     goff[j], soff, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane) xs[c * planeS + j * 64 + lane] = 0.f;
+      }
+    }
+  };
+
+  const int nchunks = a.nchunks;
+  stage(0, smem);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* cur = smem + (ch & 1) * stage_floats;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((ch + 1) & 1) * stage_floats);
+
+    constexpr int QS = CC / 2;
+    // step q: channel pair (2q, 2q+1); operands of step q+1 are fetched under the MFMAs of q
+    auto fetch = [&](int q, float (&av)[MF][4], float (&dv)[NF][4]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) av[mf][t] = cur[abase + (t * CC + 2 * q) * BM + mf * 32];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dv[nf][k] = cur[lanebase[nf] + k * fstride + 2 * q * planeS];
+    };
+    float av[2][MF][4], dv[2][NF][4];
+    fetch(0, av[0], dv[0]);
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      if (q + 1 < QS) fetch(q + 1, av[(q + 1) & 1], dv[(q + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const float d0 = dv[q & 1][nf][0], d1 = dv[q & 1][nf][1], d2 = dv[q & 1][nf][2],
+                    d3 = dv[q & 1][nf][3];
+        const float D[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+            acc[mf][nf][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][mf][t], D[t],
+                                                                  acc[mf][nf][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: y[2p] = m0+m1+m2, y[2p+1] = m1-m2-m3 ---------------------------------------
+  unsigned yvoff[NF];
+  bool pvalid[NF], p2valid[NF];
+  const unsigned half_rows = (unsigned)half * 4u * (unsigned)a.y_cstride * 4u;
+  const unsigned frame_bytes = (unsigned)(a.yHf * a.yWf) * 4u;
+  const int To_full = a.yst;     // launcher passes the un-paired frame count here
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BNP / WN) + nf * 32 + l31;
+    const int tw = p & ((1 << a.lTW) - 1);
+    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    const int n = n0 + tn, tp = ot0 + tt, oh = oh0 + th, ow = ow0 + tw;
+    pvalid[nf] = n < a.N && 2 * tp < To_full && oh < a.Ho && ow < a.Wo;
+    p2valid[nf] = pvalid[nf] && 2 * tp + 1 < To_full;
+    const long e = (long)tn * a.y_nstride + ((long)(2 * tp) * a.yHf + oh) * a.yWf + ow;
+    yvoff[nf] = pvalid[nf] ? (unsigned)(e * 4) + half_rows : OOB;
+  }
+
+  const bool want_stats = a.stats != nullptr;
+  float* red = smem;
+  if (want_stats) __syncthreads();
+
+  auto emit = [&](auto acc_tag) {
+    constexpr bool ACCUM = decltype(acc_tag)::value;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);
+        const int ml = rowu + 4 * half;
+        const int co = cout0 + ml;
+        const bool cok = co < a.Cout;
+        const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+        float s = 0.f, ss = 0.f;
+        float bia = 0.f, sc = 1.f, sf = 0.f;
+        if (a.bias && cok) bia = a.bias[co];
+        if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const float m0 = acc[mf][nf][0][i], m1 = acc[mf][nf][1][i], m2 = acc[mf][nf][2][i],
+                      m3 = acc[mf][nf][3][i];
+          float v0 = (m0 + m1) + m2, v1 = (m1 - m2) - m3;
+          const unsigned vo0 = cok ? yvoff[nf] : OOB;
+          const unsigned vo1 = (cok && p2valid[nf]) ? yvoff[nf] + frame_bytes : OOB;
+          if (ACCUM) {
+            v0 += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo0, soff, 0));
+            v1 += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo1, soff, 0));
+          }
+          const float u0 = pvalid[nf] ? v0 : 0.f, u1 = p2valid[nf] ? v1 : 0.f;
+          s += u0 + u1; ss += u0 * u0 + u1 * u1;
+          v0 = (v0 + bia) * sc + sf;
+          v1 = (v1 + bia) * sc + sf;
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), ry, vo0, soff, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), ry, vo1, soff, 0);
+        }
+        if (want_stats) {
+          s = row16_sum(s);
+          ss = row16_sum(ss);
+          if ((lane & 15) == 0) {
+            const int slot = wn * 2 + (l31 >> 4);
+            red[(slot * BM + ml) * 2 + 0] = s;
+            red[(slot * BM + ml) * 2 + 1] = ss;
+          }
+        }
+      }
+    }
+  };
+  if (a.accumulate) emit(std::true_type{}); else emit(std::false_type{});
+
+  if (want_stats) {
+    __syncthreads();
+    if (tid < BM) {
+      const int co = cout0 + tid;
+      if (co < a.Cout) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s += red[(k * BM + tid) * 2];
+          ss += red[(k * BM + tid) * 2 + 1];
+        }
+        a.stats[(long)co * a.ntiles + ntile] = s;
+        a.stats[((long)a.Cout + co) * a.ntiles + ntile] = ss;
+      }
+    }
+  }
+}
+
+template <int CC, int BM, int BNP, int PCH, bool XV4>
+int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
+  if (p.plane > PCH * 64) return COCLR_EINVAL;
+  a.mtiles = cdiv(a.Cout, BM);
+  // 16-byte staging packs the channel rows back to back
+  a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;
+  a.nchunks = cdiv(a.Cin, CC);
+  const size_t stage = ((size_t)4 * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
+  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
+  const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
+  const size_t lds = lds_main > lds_red ? lds_main : lds_red;
+  if (lds > 160 * 1024) return COCLR_EINVAL;
+  auto kern = conv_wino_t_kernel<CC, BM, BNP, PCH, XV4>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((long)a.mtiles * a.ntiles)), dim3(256), lds, stream, a);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // Stem kernel: spatial (1,KH,KW) stencil over a handful of input channels (Cin = 3:
 // backbone/s3dg.py:145 Conv_1a.conv1, and the five slices of resnet_2d3d.py:138).
 //
@@ -704,7 +1031,7 @@ int launch_stem(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst,
                                     int Cout, int Cin, int taps, long co_stride, long ci_stride,
                                     int tap_base, int tap_step, int RP, int CP, int transpose,
-                                    int row0, int col0, int rows, int cols) {
+                                    int row0, int col0, int rows, int cols, int wino) {
   // (rows, cols) = extent written per tap: the padded operand when it stands alone, only the
   // real sub-block when it is placed inside a wider (pre-zeroed) operand
   const long total = (long)taps * rows * cols;
@@ -715,7 +1042,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int rr = (int)(q % rows);
     const int tap = (int)(q / rows);
     float v = 0.f;
-    if (!transpose) {
+    if (wino) {
+      // 4 transformed matrices of a 3-tap temporal stencil (taps == 4 here): G0 = w0,
+      // G1 = (w0+w1+w2)/2, G2 = (w0-w1+w2)/2, G3 = w2; the data gradient uses the flipped stencil
+      const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
+      if (ok) {
+        const float* src = transpose ? w + rr * co_stride + c * ci_stride
+                                     : w + c * co_stride + rr * ci_stride;
+        float w0 = src[tap_base], w1 = src[tap_base + tap_step], w2 = src[tap_base + 2 * tap_step];
+        if (transpose) { const float t_ = w0; w0 = w2; w2 = t_; }
+        v = tap == 0 ? w0 : tap == 1 ? 0.5f * ((w0 + w1) + w2) : tap == 2 ? 0.5f * ((w0 - w1) + w2) : w2;
+      }
+    } else if (!transpose) {
       if (rr < Cin && c < Cout) v = w[c * co_stride + rr * ci_stride + tap_base + tap * tap_step];
     } else {
       if (rr < Cout && c < Cin)
@@ -794,6 +1132,7 @@ Choice choose_tile(const ConvPlan& base, int kt, int kh, int kw, bool has128x128
 }  // namespace
 
 extern "C" int coclr_conv_packed_size(int cin, int cout, int taps, int transpose, int64_t* elems) {
+  transpose &= 1;
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
   const long RP = pad_to(r, 32), CP = pad_to(c, 128);
   *elems = (int64_t)taps * RP * CP;
@@ -804,6 +1143,9 @@ extern "C" int coclr_conv_pack_weights(const float* w, float* packed, int cout, 
                                        int64_t co_stride, int64_t ci_stride, int tap_base,
                                        int tap_step, int transpose, int row0, int rows_total,
                                        int col0, int cols_total, void* stream) {
+  const int wino = (transpose >> 1) & 1;       // bit 1: temporal Winograd operand (taps must be 4)
+  transpose &= 1;
+  if (wino && taps != 4) return COCLR_EINVAL;
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
   const bool placed = rows_total > 0 && cols_total > 0;
   if (placed && (row0 < 0 || col0 < 0 || row0 + r > rows_total || col0 + c > cols_total))
@@ -815,7 +1157,7 @@ extern "C" int coclr_conv_pack_weights(const float* w, float* packed, int cout, 
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
                      packed, cout, cin, taps, (long)co_stride, (long)ci_stride, tap_base, tap_step,
-                     RP, CP, transpose, placed ? row0 : 0, placed ? col0 : 0, rows, cols);
+                     RP, CP, transpose, placed ? row0 : 0, placed ? col0 : 0, rows, cols, wino);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
@@ -844,6 +1186,16 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
     conv_pick_box(p, c.lbn, 1, 3, 3);
     if (c.lbn == 6) *variant = p->plane <= 256 ? 12 : 13;
     else *variant = c.bm == 128 ? 10 : 11;
+  } else if (kt == 3 && kh == 1 && kw == 1 && d->algo == 1) {
+    // temporal Winograd F(2,3): plan over frame PAIRS as a (4,1,1) stencil with stride 2
+    if (!(p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 1 && p->dt == 1 && p->dh == 1 &&
+          p->dw == 1 && p->Ti == p->To && d->ys_t == 0))
+      return COCLR_EINVAL;
+    p->To = (p->To + 1) / 2;
+    p->st = 2;
+    conv_pick_box(p, 6, 4, 1, 1);
+    if (p->plane > 256) return COCLR_EINVAL;
+    *variant = 50;
   } else if (kt == 3 && kh == 1 && kw == 1) {
     c = choose_tile(*p, 3, 1, 1, true, true, 256, 256);
     conv_pick_box(p, c.lbn, 3, 1, 1);
@@ -947,6 +1299,17 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
     case 21: return launch_variant<3, 1, 1, 8, 64, 128, 4>(a, p, stream);
     case 22: return launch_variant<3, 1, 1, 8, 64, 64, 4>(a, p, stream);
     case 25: return launch_variant<4, 1, 1, 8, 64, 128, 4>(a, p, stream);
+    case 50: {
+      // a.To = frame pairs; the kernel finds the frame count in yst and the plane pitch in yHf/yWf
+      a.yst = d->To; a.yHf = p.Ho; a.yWf = p.Wo;
+      a.y_cstride = d->To * p.Ho * p.Wo;
+      a.st = 1;
+      const bool xv4 = p.Hi == 1 && p.WH == 1 && p.lTW >= 2 && (p.Wi % 4) == 0 &&
+                       (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 &&
+                       (p.plane % 4) == 0;
+      return xv4 ? launch_wino_t<16, 64, 64, 4, true>(a, p, stream)
+                 : launch_wino_t<16, 64, 64, 4, false>(a, p, stream);
+    }
     case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);
     case 31: return launch_stem<7, 7, 3, 20>(a, p, stream);
     case 40: return launch_variant<7, 1, 1, 8, 64, 128, 8>(a, p, stream);

@@ -227,10 +227,16 @@ class Run:
             store[1][key] = buf
         return buf
 
-    def pack(self, w, transpose, kt_slice=None, taps=None, tap_base=0, tap_step=1):
+    def pack(self, w, transpose, kt_slice=None, taps=None, tap_base=0, tap_step=1, algo=0):
         """[Cout][Cin][taps] -> [taps][Cin'][Cout'] (or the dgrad operand).  kt_slice picks
-        one temporal slice of the stencil; (taps, tap_base, tap_step) an arithmetic subset."""
+        one temporal slice of the stencil; (taps, tap_base, tap_step) an arithmetic subset;
+        algo=1 the four Winograd F(2,3) matrices of a (3,1,1) stencil."""
         cout, cin, kt, kh, kw = w.shape
+        if algo == 1:
+            n = ops.conv_packed_size(cin, cout, 4, transpose)
+            packed = self._packed_buffer(w, ("wino", bool(transpose)), n, False)
+            ops.conv_pack_weights(w, packed, cout, cin, 4, cin * 3, 3, 0, int(bool(transpose)) | 2, 1)
+            return packed
         if taps is not None:
             base = tap_base
         elif kt_slice is None:
@@ -336,7 +342,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
             last = t == len(geoms) - 1
             if training and last:
                 stats = run.empty(2 * Cout * g.ntiles())
-            ops.conv_fwd(g, xv, run.pack(w, False, t if sliced else None), y,
+            ops.conv_fwd(g, xv, run.pack(w, False, t if sliced else None, algo=g.algo), y,
                          stats=stats if last else None, n_index=n_index, accumulate=t > 0)
         if training:
             if bn.momentum is None:
@@ -356,7 +362,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                            Cout, mean, invstd, scale, shift)
         for t, g in enumerate(geoms):
             last = t == len(geoms) - 1
-            ops.conv_fwd(g, xv, run.pack(w, False, t if sliced else None), zv,
+            ops.conv_fwd(g, xv, run.pack(w, False, t if sliced else None, algo=g.algo), zv,
                          ep_scale=scale if last else None, ep_shift=shift if last else None,
                          relu=relu and last, n_index=n_index, accumulate=t > 0)
 
@@ -400,7 +406,8 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                         ops.conv_fwd(pg, dy, run.pack(w, True, taps=nk, tap_base=k0,
                                                       tap_step=step), dx, accumulate=acc)
                 else:
-                    ops.conv_fwd(geoms[0].dgrad(), dy, run.pack(w, True), dx, accumulate=acc)
+                    dg = geoms[0].dgrad()
+                    ops.conv_fwd(dg, dy, run.pack(w, True, algo=dg.algo), dx, accumulate=acc)
 
         run.record(backward)
     elif y is not None:

@@ -6,6 +6,7 @@ kernel on torch's *current* stream.  Nothing is computed in Python or by
 ATen, and there is no CPU path: host tensors are rejected.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -49,13 +50,25 @@ def _chk5(t, name):
     return s[0] if n > 1 else max(s[0], c * d * h * w)
 
 
+WINOGRAD = os.environ.get("COCLR_WINOGRAD", "1") != "0"
+
+
+def winograd_ok(cin, k, s, p, d, lattice):
+    """(3,1,1) stride-1 pad-1 convolutions (the temporal half of every STConv3d,
+    backbone/s3dg.py:41) can run as Winograd F(2,3) along T: 4 channel contractions per pair of
+    output frames instead of 6.  Narrow layers stay direct (the kernel stages 16 channels at a
+    time)."""
+    return (WINOGRAD and tuple(k) == (3, 1, 1) and tuple(s) == (1, 1, 1) and tuple(p) == (1, 0, 0)
+            and tuple(d) == (1, 1, 1) and lattice is None and cin >= 16)
+
+
 class ConvGeom:
     """Geometry of one 3D convolution (python mirror of coclr_conv_desc)."""
 
-    __slots__ = ("N", "Cin", "Cout", "idim", "odim", "k", "s", "p", "d", "lattice", "desc",
+    __slots__ = ("N", "Cin", "Cout", "idim", "odim", "k", "s", "p", "d", "lattice", "algo", "desc",
                  "_cache")
 
-    def __init__(self, N, Cin, Cout, idim, k, s, p, d=(1, 1, 1), odim=None, lattice=None):
+    def __init__(self, N, Cin, Cout, idim, k, s, p, d=(1, 1, 1), odim=None, lattice=None, algo=0):
         self.N, self.Cin, self.Cout = int(N), int(Cin), int(Cout)
         self.idim = tuple(int(v) for v in idim)
         self.k, self.s, self.p, self.d = (tuple(int(v) for v in t) for t in (k, s, p, d))
@@ -71,8 +84,12 @@ class ConvGeom:
         self.lattice = lattice
         lat = (0,) * 9 if lattice is None else tuple(lattice[0]) + tuple(lattice[1]) + \
             tuple(lattice[2])
+        # algo 1 = Winograd F(2,3) along T (see winograd_ok); the packed operand differs
+        self.algo = int(algo)
+        if self.algo == 1 and not winograd_ok(self.Cin, self.k, self.s, self.p, self.d, lattice):
+            raise ValueError("coclr_amd: temporal Winograd needs a (3,1,1) stride-1 pad-1 stencil")
         self.desc = ConvDesc(self.N, self.Cin, self.Cout, *self.idim, *self.odim, *self.k,
-                             *self.s, *self.p, *self.d, 0, 0, *lat, 0)
+                             *self.s, *self.p, *self.d, 0, 0, *lat, 0, self.algo)
         self._cache = {}
 
     @property
@@ -87,8 +104,10 @@ class ConvGeom:
             pad = tuple(self.k[i] - 1 - self.p[i] for i in range(3))
             if min(pad) < 0:
                 raise ValueError("coclr_amd: padding larger than kernel-1 is not supported")
+            algo = 1 if self.algo == 1 and winograd_ok(self.Cout, self.k, (1, 1, 1), pad, self.s,
+                                                       None) else 0
             g = ConvGeom(self.N, self.Cout, self.Cin, self.odim, self.k, (1, 1, 1), pad,
-                         d=self.s, odim=self.idim)
+                         d=self.s, odim=self.idim, algo=algo)
             self._cache["dgrad"] = g
         return g
 
@@ -153,13 +172,14 @@ _GEOMS = {}
 
 def conv_geom(N, Cin, Cout, idim, k, s, p):
     """Shared, cached ConvGeom (its ntiles / dgrad / phase plans are computed once): the engine
-    asks for the same ~80 geometries every step."""
+    asks for the same ~80 geometries every step.  Picks the algorithm (direct / Winograd)."""
     key = (N, Cin, Cout, tuple(idim), tuple(k), tuple(s), tuple(p))
     g = _GEOMS.get(key)
     if g is None:
         if len(_GEOMS) > 8192:
             _GEOMS.clear()
-        g = _GEOMS[key] = ConvGeom(N, Cin, Cout, idim, k, s, p)
+        algo = 1 if winograd_ok(Cin, k, s, p, (1, 1, 1), None) else 0
+        g = _GEOMS[key] = ConvGeom(N, Cin, Cout, idim, k, s, p, algo=algo)
     return g
 
 

@@ -132,14 +132,30 @@ def compare_step(rec, kind, out, tgt, loss, named_grads, tol=REL_TOL, truth=None
         check_close(loss, rec["loss"], max(tol, 2e-3), "loss")
     if truth is None:
         return
+    # Near-tie ReLU / max-pool decisions make single tensors jump by percents when ANY fp32
+    # evaluation re-associates a sum (each one flips its own handful of elements; with 8-32
+    # values per BatchNorm channel in the last stage one flipped element is visible).  So the
+    # bound is on the distribution over the sampled tensors, not on each tensor: median within
+    # grad_factor x the reference's own median error (+ floor), no tensor beyond 0.1, and at most
+    # a fifth of the sampled tensors outside the per-tensor bound (observed: 0-2 of 10, a different
+    # pair for every summation order -- direct vs Winograd, tile shapes, fused heads).
+    got, refs, outliers = [], [], []
     for k, ref in rec["grads"].items():
         t = sample(truth[k])
         e_ref = rel_err(ref, t)
         e_got = rel_err(sample(named_grads[k]), t)
         if report is not None:
             report.append((k, e_got, e_ref))
-        assert e_got <= grad_factor * e_ref + grad_floor, \
-            "grad %s: err vs fp64 truth %.3e, reference's own fp32 err %.3e" % (k, e_got, e_ref)
+        got.append(e_got)
+        refs.append(e_ref)
+        assert e_got <= 0.1, "grad %s: err vs fp64 truth %.3e (reference fp32: %.3e)" % (k, e_got, e_ref)
+        if e_got > grad_factor * e_ref + grad_floor:
+            outliers.append((k, e_got, e_ref))
+    med_got = sorted(got)[len(got) // 2]
+    med_ref = sorted(refs)[len(refs) // 2]
+    assert med_got <= grad_factor * med_ref + grad_floor, \
+        "median grad err vs fp64 truth %.3e, reference's own %.3e" % (med_got, med_ref)
+    assert len(outliers) <= max(1, len(got) // 5), "gradient outliers: %s" % outliers
 
 
 def compare_state(rec, sd, B_world, K, tol=REL_TOL):

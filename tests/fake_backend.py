@@ -22,12 +22,24 @@ def _r128(v):
 
 
 def conv_packed_size(cin, cout, taps, transpose):
-    r, c = (cout, cin) if transpose else (cin, cout)
+    r, c = (cout, cin) if int(transpose) & 1 else (cin, cout)
     return taps * _r32(r) * _r128(c)
 
 
 def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose,
                       tap_step=1, row0=0, rows_total=0, col0=0, cols_total=0):
+    wino = bool(int(transpose) & 2)
+    transpose = bool(int(transpose) & 1)
+    if wino:
+        # the double keeps the plain 3-tap stencil in the first three slots of the 4-slot operand
+        taps_src = 3
+        w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, 3), (co_stride, ci_stride, 1), 0)
+        r, c = (cout, cin) if transpose else (cin, cout)
+        dst = packed.view(4, _r32(r), _r128(c))
+        dst.zero_()
+        src = w3.flip(2).permute(2, 0, 1) if transpose else w3.permute(2, 1, 0)
+        dst[:3, :r, :c] = src
+        return
     w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, taps),
                           (co_stride, ci_stride, tap_step), tap_base)
     r, c = (cout, cin) if transpose else (cin, cout)
@@ -41,6 +53,9 @@ def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base
 
 def _unpack(geom, wp):
     taps = geom.taps
+    if getattr(geom, "algo", 0) == 1:
+        w = wp.view(4, _r32(geom.Cin), _r128(geom.Cout))[:3, :geom.Cin, :geom.Cout]
+        return w.permute(2, 1, 0).reshape(geom.Cout, geom.Cin, *geom.k).contiguous()
     w = wp.view(taps, _r32(geom.Cin), _r128(geom.Cout))[:, :geom.Cin, :geom.Cout]
     return w.permute(2, 1, 0).reshape(geom.Cout, geom.Cin, *geom.k).contiguous()
 

@@ -455,3 +455,41 @@ def test_self_gating_kernels():
     ops.sigmoid_bwd(dev(dw), w, ds)
     sg = torch.sigmoid(s_)
     close(ds, dw * sg * (1 - sg), what="sigmoid backward")
+
+
+WINO_CASES = [(2, 192, 192, (8, 8, 8)), (3, 208, 208, (4, 8, 8)), (2, 48, 48, (2, 4, 4)),
+              (2, 64, 64, (3, 7, 7)), (2, 64, 96, (5, 6, 10)), (4, 32, 24, (16, 4, 4)),
+              (2, 128, 128, (1, 4, 4))]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "%d_%d_%d_%s" % c)
+def test_conv_temporal_winograd(case):
+    """(3,1,1) stride-1 pad-1 convolutions through Winograd F(2,3) along T (algo = 1): forward
+    with BatchNorm partial sums, accumulate form, and the data gradient -- odd frame counts,
+    ragged channel counts, a single frame."""
+    from coclr_amd import ops, engine
+    N, Cin, Cout, dims = case
+    k, s, p = (3, 1, 1), (1, 1, 1), (1, 0, 0)
+    torch.manual_seed(6)
+    x = torch.randn(N, Cin, *dims, requires_grad=True)
+    w = (torch.randn(Cout, Cin, *k) * 0.05).requires_grad_(True)
+    ref = F.conv3d(x, w, None, s, p)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    g = ops.conv_geom(N, Cin, Cout, dims, k, s, p)
+    assert g.algo == 1 and g.dgrad().algo == 1
+    run = engine.Run(torch.device("cuda"), save=False)
+    wd, xd, dyd = dev(w.detach()), dev(x.detach()), dev(dy)
+    y = torch.full((N, Cout, *g.odim), float("nan"), device="cuda")
+    stats = torch.empty(2 * Cout * g.ntiles(), device="cuda")
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, stats=stats)
+    close(y, ref, what="winograd fwd")
+    st = stats.view(2, Cout, -1).double().sum(-1).cpu()
+    close(st[0], ref.double().sum((0, 2, 3, 4)), rtol=1e-3, what="stats sum")
+    close(st[1], (ref.double() ** 2).sum((0, 2, 3, 4)), what="stats sumsq")
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, accumulate=True)
+    close(y, 2 * ref, what="winograd accumulate")
+    dx = torch.full((N, Cin, *dims), float("nan"), device="cuda")
+    dg = g.dgrad()
+    ops.conv_fwd(dg, dyd, run.pack(wd, True, algo=1), dx)
+    close(dx, x.grad, what="winograd dgrad")

@@ -43,12 +43,12 @@ only = sys.argv[1:]
 print("%-16s %9s | %8s %7s | %8s %7s | %8s %7s" % ("layer", "GF", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
 for name, cin, cout, k, s, p, idim in L:
     if only and not any(o in name for o in only): continue
-    g = ops.ConvGeom(B, cin, cout, idim, k, s, p)
+    g = ops.conv_geom(B, cin, cout, idim, k, s, p)
     x = torch.randn(B, cin, *idim, device=dev)
     w = torch.randn(cout, cin, *k, device=dev) * 0.05
     y = torch.empty(B, cout, *g.odim, device=dev)
     stats = torch.empty(2 * cout * g.ntiles(), device=dev)
-    wp = run.pack(w, False); wpt = run.pack(w, True)
+    wp = run.pack(w, False, algo=g.algo); wpt = run.pack(w, True, algo=g.dgrad().algo)
     gf = 2.0 * B * cout * cin * k[0]*k[1]*k[2] * g.odim[0]*g.odim[1]*g.odim[2] / 1e9
     tf = timeit(lambda: ops.conv_fwd(g, x, wp, y, stats=stats))
     dy = torch.randn_like(y); dx = torch.empty_like(x)

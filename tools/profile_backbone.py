@@ -25,7 +25,7 @@ def wrap(name):
         if isinstance(g, ops.ConvGeom):
             key = "%d->%d k%s s%s d%s in%s%s" % (g.Cin, g.Cout, "x".join(map(str, g.k)), "x".join(map(str, g.s)),
                                               "x".join(map(str, g.d)), "x".join(map(str, g.idim)),
-                                              " lat" if g.lattice else "")
+                                              (" lat" if g.lattice else "") + (" wino" if g.algo else ""))
             flops = 2.0 * g.N * g.Cin * g.Cout * g.taps * g.odim[0] * g.odim[1] * g.odim[2]
             if g.d != (1, 1, 1):   # dilated dgrad: useful flops are those of the forward conv
                 flops /= (g.d[0] * g.d[1] * g.d[2])
