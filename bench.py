@@ -221,15 +221,17 @@ def main():
     # the same dominant kernel alone on the chip (the in-step launches above share the CUs with the
     # key-encoder / weight-gradient streams): 20 back-to-back launches of Conv_2c.conv1
     iso_ms = None
+    iso_algo = 0
     if rank == 0 and args.net == "s3d":
         from coclr_amd import ops, engine
-        g = ops.ConvGeom(B, 64, 192, (tq, hq, hq), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        g = ops.conv_geom(B, 64, 192, (tq, hq, hq), (1, 3, 3), (1, 1, 1), (0, 1, 1))   # as the model
         run = engine.Run(device, save=False)
         xi = torch.randn(B, 64, tq, hq, hq, device=device)
         wi = torch.randn(192, 64, 1, 3, 3, device=device) * 0.05
         yi = torch.empty(B, 192, *g.odim, device=device)
         sti = torch.empty(2 * 192 * g.ntiles(), device=device)
-        wpi = run.pack(wi, False)
+        wpi = run.pack(wi, False, algo=g.algo)
+        iso_algo = g.algo
         timer.enabled = False
         for _ in range(3):
             ops.conv_fwd(g, xi, wpi, yi, stats=sti)
@@ -247,13 +249,20 @@ def main():
         clips = B * world * args.steps / dt
         kms = timer.mean_ms()
         flops = 2.0 * B * 192 * 64 * 9 * tq * hq * hq          # algorithmic, per launch
+        wino = bool(iso_ms) and iso_algo == 1
+        kname = ("conv_wino_hw_kernel<8,10> Winograd F(2x2,3x3)" if wino
+                 else "conv_igemm_kernel<1,3,3,8,64,128,4>")
         roof = None
         traffic = None
+        tj = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath) and args.net == "s3d" and B == 32:
             # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
             # (counters cannot be read from inside the process)
             tj = json.load(open(tpath))
+            if wino != ("wino" in tj["kernel"]):
+                tj = None
+        if tj is not None:
             traffic = {"bytes_per_launch": tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"],
                        "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
                        "source": tj["source"]}
@@ -262,11 +271,15 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic,
-                    "kernel": "conv_igemm_kernel<1,3,3,8,64,128,4> (Conv_2c.conv1 64->192, %dx%dx%d, "
+                    "kernel": "%s (Conv_2c.conv1 64->192, %dx%dx%d, "
                               "N=%d; the query encoder's launches inside the timed steps, which share "
-                              "the chip with the key-encoder stream)" % (tq, hq, hq, B),
+                              "the chip with the key-encoder stream)" % (kname, tq, hq, hq, B),
                     "launches_timed": len(timer.events), "avg_launch_ms": round(kms, 4),
                     "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
+            if wino:
+                # algorithmic = the direct convolution's FLOPs; the kernel issues 16/36 of them as MFMAs
+                roof["mfma_gflop_per_launch"] = round(flops * 16.0 / 36.0 / 1e9, 2)
+                roof["mfma_frac"] = round(ach * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS, 4)
             if iso_ms:
                 # same kernel, same geometry, nothing else running: the kernel's own efficiency
                 roof["isolated"] = {"avg_launch_ms": round(iso_ms, 4),

@@ -34,6 +34,7 @@
 //     accumulate, plus per-workgroup partial sums (sum, sum of squares) per
 //     output channel for train-mode BatchNorm, reduced with DPP row operations
 //     and written without atomics as [2][Cout][ntiles].
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -164,19 +165,32 @@ conv_igemm_kernel(const ConvArgs a) {
   }
   // weights: lane's row inside a piece and column
   const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
-  // XV4 (pointwise, box = a run of BN contiguous positions, everything 16-byte aligned): the
-  // window IS the box, staged with 16-byte DMA -- one piece = 256/BN channel rows
-  unsigned xv4off = OOB;
-  int xv4c = 0;
+  // XV4: stencils that do not reach along the flattened (H,W) axis (pointwise and temporal
+  // ones) have windows without a W halo; with everything 16-byte aligned the LDS image
+  // [c][plane] is filled by 16-byte DMA in 1 KiB pieces that run across channel rows: piece j,
+  // lane L holds floats 256j + 4L .. +3 of the chunk image.  Wave w owns pieces w, w+4, ...
+  constexpr int PV = XV4 ? (CC * PCH * 64 / 256 + 3) / 4 : 1;
+  unsigned xvoff[PV];
+  int xvc[PV];
   if (XV4) {
-    const int e = (lane % (BN / 4)) * 4;
-    xv4c = lane / (BN / 4);
-    const int wn_ = e >> a.lTW;                 // plane1 == 1 << lTW here
-    const int iw = ow0 + (e & ((1 << a.lTW) - 1));
-    const int n = n0 + wn_;
-    if (n < a.N && iw < a.Wi) {
-      const long ns = gather ? (long)a.n_index[n] : (long)wn_;
-      xv4off = (unsigned)((ns * a.x_nstride + iw + (long)xv4c * a.x_cstride) * 4);
+#pragma unroll
+    for (int jj = 0; jj < PV; ++jj) {
+      const int flat = (wave + 4 * jj) * 256 + lane * 4;
+      const int c = flat / plane, e = flat - c * plane;
+      unsigned off = OOB;
+      if (c < CC) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        const int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_ww);              // WH == 1 here
+        const int ww = q - wt * a.WW;
+        const int n = n0 + wn_, it = vt0 + wt, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && iw < a.Wi) {
+          const long ns = gather ? (long)a.n_index[n] : (long)wn_;
+          off = (unsigned)((ns * a.x_nstride + (long)it * a.Wi + iw + (long)c * a.x_cstride) * 4);
+        }
+      }
+      xvoff[jj] = off;
+      xvc[jj] = c;
     }
   }
 
@@ -214,12 +228,14 @@ conv_igemm_kernel(const ConvArgs a) {
     // input window: channels wave, wave+4, ...
     float* xs = sbase + W_FLOATS;
     if (XV4) {
-      constexpr int CPP = 256 / BN;              // channel rows per 1 KiB piece
-      for (int p = wave; p < CC / CPP; p += 4) {
-        const int cin = cin0 + p * CPP;
-        const unsigned vo = cin + xv4c < a.Cin ? xv4off : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + p * 256), 16, vo,
-                                                 (unsigned)cin * (unsigned)a.x_cstride * 4u, 0, 0);
+      const unsigned soff = (unsigned)cin0 * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+      for (int jj = 0; jj < PV; ++jj) {
+        const int j = wave + 4 * jj;
+        if (j * 256 < CC * plane && xvc[jj] < CC) {   // exec-masked: lanes past the image write nothing
+          const unsigned vo = cin0 + xvc[jj] < a.Cin ? xvoff[jj] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + j * 256), 16, vo, soff, 0, 0);
+        }
       }
     } else
 #pragma unroll
@@ -696,6 +712,416 @@ int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------
+// Spatial (1,3,3) stride-1 pad-1 convolutions through Winograd F(2x2,3x3).
+//
+// A 2x2 block of outputs needs the 4x4 input patch d starting one row/column before it and
+// SIXTEEN channel contractions instead of 36:
+//     V = B^T d B        (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3, applied to rows then columns)
+//     M[xi] = U[xi] V[xi]   summed over input channels, xi = 4i+j, U = G g G^T (packed operand)
+//     Y = A^T M A        (A^T rows: m0+m1+m2, m1-m2-m3)
+// 2.25x fewer MFMAs for the (1,3,3) layers -- the largest share of the S3D conv FLOPs -- in the
+// forward and data-gradient passes.  fp32 throughout.
+//
+// Seen from the implicit-GEMM kernel this is a (1,4,4) stencil with stride (1,2,2) over "block
+// positions" (Ho/2 x Wo/2 per frame): same box / window / LDS-DMA staging.  A wave owns ONE
+// 32(cout) x 32(block positions) MFMA tile and keeps all 16 transform-domain accumulators of it
+// (256 registers -> one workgroup per CU); the 4x4 patch is read from the LDS window as eight
+// ds_read_b64 and transformed in registers under the MFMAs of the previous step; the epilogue
+// applies A^T . A and stores row pairs as 8-byte buffer stores.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// One element of an accumulator set, read where the program says so: left to itself the
+// compiler copies whole 16-register sets out of the AGPRs, 256 VGPRs at the epilogue's peak.
+__device__ __forceinline__ float agpr_read(float x) {
+  float r;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
+  return r;
+}
+
+constexpr int kWinoGrid = 256;    // persistent grid: one workgroup per CU
+
+template <int CC, int PCH>
+__global__ void __launch_bounds__(256)
+conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
+  constexpr int TAPS = 16;
+  constexpr int BM = 64;
+  constexpr int RPP = 256 / BM;
+  constexpr int WPIECES = TAPS * CC / RPP;
+  static_assert(CC % RPP == 0 && CC % 4 == 0, "chunk shape");
+  constexpr int W_FLOATS = TAPS * CC * BM;
+  constexpr int QS = CC / 2;
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeS = a.planeS;
+  const int stage_floats = W_FLOATS + CC * planeS;
+  float* red = smem + 2 * stage_floats;     // [4][BM][2] statistics scratch, never DMA'd over
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int plane = a.plane;
+  const int WW = a.WW;
+
+  // The workgroup is PERSISTENT: the 16 accumulator sets leave room for one workgroup per CU,
+  // so nothing else on the CU would hide its prologue, its epilogue or the launch of its
+  // successor, and workgroups marching in lockstep would hit HBM with their stores all at once.
+  // It walks tiles L, L+grid, ... and treats their channel chunks as ONE stream through the two
+  // LDS stages: the first chunk of the next tile is requested before the epilogue of the current
+  // one, and the transformed outputs stay in registers until they are stored under the MFMAs of
+  // the next tile's first two chunks.  L keeps the workgroups of one XCD (blockIdx % 8) on
+  // neighbouring tiles: the cout tiles of a box share their window through that XCD's L2.
+  const int nwg = (int)gridDim.x;
+  int tile = (nwg % 8 == 0) ? ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  if (tile >= total_tiles) return;
+
+  const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
+
+  // tile-independent half of the window gather: the window coordinates (n, t, h, w) of the
+  // elements this lane fetches, packed one byte each, parked in LDS
+  unsigned* wtab = reinterpret_cast<unsigned*>(red + 4 * BM * 2);     // [PCH][256]
+  {
+    const int hw = a.WH * WW;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int e = j * 64 + lane;
+      unsigned crd = 0xffffffffu;
+      if (e < plane) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
+        const int wh = fdiv(q, a.inv_ww);
+        const int ww = q - wh * WW;
+        crd = (unsigned)ww | ((unsigned)wh << 8) | ((unsigned)wt << 16) | ((unsigned)wn_ << 24);
+      }
+      wtab[j * 256 + tid] = crd;
+    }
+  }
+
+  // block position of this lane inside a box: window offset of the top-left element of its
+  // 4x4 patch, and its coordinates
+  int lanebase, ptw, pth, ptt, ptn;
+  {
+    const int p = wn * 32 + l31;
+    ptw = p & ((1 << a.lTW) - 1);
+    pth = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    ptt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    ptn = p >> (a.lTW + a.lTH + a.lTT);
+    lanebase = W_FLOATS + ptn * a.plane1 + (ptt * a.WH + pth * 2) * WW + ptw * 2 + half * planeS;
+  }
+  const int abase = half * BM + wm * 32 + l31;
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
+
+  // ---- per-tile state ------------------------------------------------------------------
+  int ntile, n0, ot0, oh0, ow0, cout0;        // of the tile being multiplied
+  unsigned goff[PCH];
+  __amdgpu_buffer_rsrc_t rx;
+  auto setup = [&](int t) {
+    const int mt = t % a.mtiles;
+    ntile = t / a.mtiles;
+    int r = ntile;
+    const int bw_ = r % a.nbw; r /= a.nbw;
+    const int bh_ = r % a.nbh; r /= a.nbh;
+    const int bt_ = r % a.nbt; r /= a.nbt;
+    n0 = r << a.lTN;
+    ow0 = bw_ << a.lTW; oh0 = bh_ << a.lTH; ot0 = bt_ << a.lTT;      // ow0/oh0: BLOCK index
+    cout0 = mt * BM;
+    const int vt0 = ot0, vh0 = oh0 * 2 - 1, vw0 = ow0 * 2 - 1;        // window origin
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const unsigned c = wtab[j * 256 + tid];        // read back per tile: cheaper than 10 live registers
+      const int ww = (int)(c & 255u), wh = (int)((c >> 8) & 255u), wt = (int)((c >> 16) & 255u),
+                wn_ = (int)(c >> 24);
+      const int iw = vw0 + ww, ih = vh0 + wh, it = vt0 + wt, n = n0 + wn_;
+      const bool ok = c != 0xffffffffu && n < a.N && it < a.Ti && (unsigned)ih < (unsigned)a.Hi &&
+                      (unsigned)iw < (unsigned)a.Wi;
+      const long off = (long)wn_ * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw;
+      goff[j] = ok ? (unsigned)off * 4u : OOB;
+    }
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)n0 * a.x_nstride), 0, BUF_RANGE,
+                                           0x00020000);
+  };
+
+  auto stage = [&](int cin0, float* sbase) {
+    for (int p = wave; p < WPIECES; p += 4) {
+      const int row0 = p * RPP;
+      const int tap = row0 / CC, c0 = row0 % CC;
+      const unsigned soff = (unsigned)((((long)tap * a.CinP + cin0 + c0) * a.CoutP + cout0) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sbase + p * 256), 16, wvoff, soff, 0, 0);
+    }
+    float* xs = sbase + W_FLOATS;
+#pragma unroll
+    for (int ci = 0; ci < CC / 4; ++ci) {
+      const int c = ci * 4 + wave;
+      const int cin = cin0 + c;
+      if (cin < a.Cin) {
+        const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
+                                                     goff[j], soff, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane) xs[c * planeS + j * 64 + lane] = 0.f;
+      }
+    }
+  };
+
+  const int nchunks = a.nchunks;
+  const bool want_stats = a.stats != nullptr;
+  const unsigned half_rows = (unsigned)half * 4u * (unsigned)a.y_cstride * 4u;
+  const unsigned row_bytes = (unsigned)a.yWf * 4u;
+
+  // outputs of the previous tile, waiting to be stored
+  float yv[16][4];
+  unsigned pend_vo0 = OOB, pend_vo1 = OOB;   // lane offsets of the pending block (rows 2oh, 2oh+1)
+  int pend_co0 = 0;                          // first output channel of this wave's 32 rows
+  __amdgpu_buffer_rsrc_t pend_ry = rw;
+  bool pending = false;
+  auto flush = [&](auto lo_tag) {
+    constexpr int LO = decltype(lo_tag)::value;
+#pragma unroll
+    for (int i = LO; i < LO + 8; ++i) {
+      // accumulator element i is output row (i&3) + 8*(i>>2), +4 in the upper half-wave
+      const int rowu = pend_co0 + (i & 3) + 8 * (i >> 2);
+      const unsigned soff = (unsigned)rowu * (unsigned)a.y_cstride * 4u;
+      const bool cok = rowu + 4 * half < a.Cout;
+      u32x2 s0, s1;
+      s0.x = __float_as_uint(yv[i][0]); s0.y = __float_as_uint(yv[i][1]);
+      s1.x = __float_as_uint(yv[i][2]); s1.y = __float_as_uint(yv[i][3]);
+      __builtin_amdgcn_raw_buffer_store_b64(s0, pend_ry, cok ? pend_vo0 : OOB, soff, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(s1, pend_ry, cok ? pend_vo1 : OOB, soff, 0);
+    }
+  };
+
+  setup(tile);
+  stage(0, smem);
+  int G = 0;      // chunks streamed so far: chunk G lives in stage G & 1
+
+  for (;;) {
+    f32x16 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    for (int ch = 0; ch < nchunks; ++ch, ++G) {
+      const float* cur = smem + (G & 1) * stage_floats;
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // this wave's DMA of the chunk has landed
+      __syncthreads();                      // ... everyone's; the other stage is fully consumed
+      if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((G + 1) & 1) * stage_floats);
+      if (pending) {
+        if (ch == 0) flush(std::integral_constant<int, 0>{});
+        if (ch == 1 || nchunks == 1) { flush(std::integral_constant<int, 8>{}); pending = false; }
+      }
+
+      // step q: channel pair (2q, 2q+1).  Two-deep software pipeline: while the 16 MFMAs of
+      // step q issue, the weights of step q+1 and the patch of step q+2 are fetched from LDS and
+      // the patch of step q+1 is transformed.
+      auto fetch_a = [&](int q, float (&av)[16]) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) av[t] = cur[abase + (t * CC + 2 * q) * BM];
+      };
+      auto fetch_d = [&](int q, float (&dv)[16]) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float* src = &cur[lanebase + rr * WW + 2 * q * planeS];
+          const float2 lo = *reinterpret_cast<const float2*>(src);
+          const float2 hi = *reinterpret_cast<const float2*>(src + 2);
+          dv[rr * 4 + 0] = lo.x; dv[rr * 4 + 1] = lo.y; dv[rr * 4 + 2] = hi.x; dv[rr * 4 + 3] = hi.y;
+        }
+      };
+      auto transform = [&](const float (&dv)[16], float (&V)[16]) {
+        float t_[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t_[0 + j] = dv[0 + j] - dv[8 + j];
+          t_[4 + j] = dv[4 + j] + dv[8 + j];
+          t_[8 + j] = dv[8 + j] - dv[4 + j];
+          t_[12 + j] = dv[4 + j] - dv[12 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          V[4 * i + 0] = t_[4 * i + 0] - t_[4 * i + 2];
+          V[4 * i + 1] = t_[4 * i + 1] + t_[4 * i + 2];
+          V[4 * i + 2] = t_[4 * i + 2] - t_[4 * i + 1];
+          V[4 * i + 3] = t_[4 * i + 1] - t_[4 * i + 3];
+        }
+      };
+      float av[2][16], V[2][16], dv[2][16];
+      fetch_d(0, dv[0]);
+      fetch_a(0, av[0]);
+      if (QS > 1) fetch_d(1, dv[1]);
+      transform(dv[0], V[0]);
+#pragma unroll
+      for (int q = 0; q < QS; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < QS) fetch_a(q + 1, av[(q + 1) & 1]);
+        if (q + 2 < QS) fetch_d(q + 2, dv[q & 1]);
+        if (q + 1 < QS) transform(dv[(q + 1) & 1], V[(q + 1) & 1]);
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t], V[q & 1][t], acc[t], 0, 0, 0);
+        // issue order: one MFMA, two LDS reads, two VALU ops of the transform
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (pending) {   // unreachable unless nchunks == 0
+      flush(std::integral_constant<int, 0>{});
+      flush(std::integral_constant<int, 8>{});
+      pending = false;
+    }
+
+    // ---- epilogue: Y = A^T M A into registers; hand the LDS stream to the next tile ---------
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.y + (long)n0 * a.y_nstride), 0, BUF_RANGE, 0x00020000);
+    unsigned yvoff;
+    bool pvalid;
+    {
+      const int n = n0 + ptn, ot = ot0 + ptt, oh = oh0 + pth, ow = ow0 + ptw;   // block coords
+      pvalid = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
+      const long e = (long)ptn * a.y_nstride + ((long)ot * a.yHf + 2 * oh) * a.yWf + 2 * ow;
+      yvoff = pvalid ? (unsigned)(e * 4) + half_rows : OOB;
+    }
+    const int e_ntile = ntile, e_cout0 = cout0;
+    const int next = tile + nwg;
+    const bool more = next < total_tiles;
+    if (more) {
+      setup(next);
+      stage(0, smem + (G & 1) * stage_floats);
+    }
+
+    // Specialised on what the launch asks for, so the common forms carry no per-element
+    // branches: MODE 0 plain, 1 batch-norm statistics (training forward), 2 everything
+    // (bias / affine / ReLU / accumulate / statistics decided at run time).
+    auto emit = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * 32 + (i & 3) + 8 * (i >> 2);
+        const int ml = rowu + 4 * half;
+        float r0[4], r1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float m0 = agpr_read(acc[0 + j][i]), m1 = agpr_read(acc[4 + j][i]),
+                      m2 = agpr_read(acc[8 + j][i]), m3 = agpr_read(acc[12 + j][i]);
+          r0[j] = (m0 + m1) + m2;
+          r1[j] = (m1 - m2) - m3;
+        }
+        float v00 = (r0[0] + r0[1]) + r0[2], v01 = (r0[1] - r0[2]) - r0[3];
+        float v10 = (r1[0] + r1[1]) + r1[2], v11 = (r1[1] - r1[2]) - r1[3];
+        if (MODE == 2) {
+          const int co = e_cout0 + ml;
+          const bool cok = co < a.Cout;
+          if (a.accumulate) {
+            const unsigned soff = (unsigned)(e_cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+            const unsigned vo0 = cok ? yvoff : OOB;
+            const unsigned vo1 = cok && pvalid ? yvoff + row_bytes : OOB;
+            const u32x2 o0 = __builtin_amdgcn_raw_buffer_load_b64(ry, vo0, soff, 0);
+            const u32x2 o1 = __builtin_amdgcn_raw_buffer_load_b64(ry, vo1, soff, 0);
+            v00 += __uint_as_float(o0.x); v01 += __uint_as_float(o0.y);
+            v10 += __uint_as_float(o1.x); v11 += __uint_as_float(o1.y);
+          }
+        }
+        if (MODE != 0 && (MODE == 1 || want_stats)) {
+          // rows past Cout hold exact zeros (zero weights); blocks past the tensor are masked
+          float s = 0.f, ss = 0.f;
+          if (pvalid) {
+            s = (v00 + v01) + (v10 + v11);
+            ss = (v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11);
+          }
+          s = row16_sum(s);
+          ss = row16_sum(ss);
+          if ((lane & 15) == 0) {
+            const int slot = wn * 2 + (l31 >> 4);
+            red[(slot * BM + ml) * 2 + 0] = s;
+            red[(slot * BM + ml) * 2 + 1] = ss;
+          }
+        }
+        if (MODE == 2) {
+          const int co = e_cout0 + ml;
+          const bool cok = co < a.Cout;
+          float bia = 0.f, sc = 1.f, sf = 0.f;
+          if (a.bias && cok) bia = a.bias[co];
+          if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+          v00 = (v00 + bia) * sc + sf; v01 = (v01 + bia) * sc + sf;
+          v10 = (v10 + bia) * sc + sf; v11 = (v11 + bia) * sc + sf;
+          if (a.relu) {
+            v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f);
+          }
+        }
+        yv[i][0] = v00; yv[i][1] = v01; yv[i][2] = v10; yv[i][3] = v11;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    const bool fancy = a.bias || a.ep_scale || a.relu || a.accumulate;
+    if (fancy) emit(std::integral_constant<int, 2>{});
+    else if (want_stats) emit(std::integral_constant<int, 1>{});
+    else emit(std::integral_constant<int, 0>{});
+    pend_ry = ry;
+    pend_vo0 = yvoff;
+    pend_vo1 = pvalid ? yvoff + row_bytes : OOB;
+    pend_co0 = e_cout0 + wm * 32;
+    pending = true;
+
+    if (want_stats) {
+      __syncthreads();
+      if (tid < BM) {
+        const int co = e_cout0 + tid;
+        if (co < a.Cout) {
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            s += red[(k * BM + tid) * 2];
+            ss += red[(k * BM + tid) * 2 + 1];
+          }
+          a.stats[(long)co * a.ntiles + e_ntile] = s;
+          a.stats[((long)a.Cout + co) * a.ntiles + e_ntile] = ss;
+        }
+      }
+    }
+    if (!more) break;
+    tile = next;
+  }
+  flush(std::integral_constant<int, 0>{});
+  flush(std::integral_constant<int, 8>{});
+}
+
+template <int CC, int PCH>
+int launch_wino_hw(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
+  if (p.plane > PCH * 64 || p.WW > 255 || p.WH > 255 || p.WT > 255 || p.lTN > 7) return COCLR_EINVAL;
+  a.mtiles = cdiv(a.Cout, 64);
+  a.planeS = cdiv(p.plane, 64) * 64;
+  a.nchunks = cdiv(a.Cin, CC);
+  const size_t stage = ((size_t)16 * CC * 64 + (size_t)CC * a.planeS) * sizeof(float);
+  // two stages + statistics scratch + window coordinate table
+  const size_t lds = 2 * stage + (size_t)4 * 64 * 2 * sizeof(float) + (size_t)PCH * 256 * sizeof(unsigned);
+  if (lds > 160 * 1024) return COCLR_EINVAL;
+  auto kern = conv_wino_hw_kernel<CC, PCH>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const long total = (long)a.mtiles * a.ntiles;
+  const int grid = total < kWinoGrid ? (int)total : kWinoGrid;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, (int)total);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // Stem kernel: spatial (1,KH,KW) stencil over a handful of input channels (Cin = 3:
 // backbone/s3dg.py:145 Conv_1a.conv1, and the five slices of resnet_2d3d.py:138).
 //
@@ -1042,7 +1468,27 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int rr = (int)(q % rows);
     const int tap = (int)(q / rows);
     float v = 0.f;
-    if (wino) {
+    if (wino && taps == 16) {
+      // U = G g G^T of a 3x3 spatial stencil (16 transform-domain matrices, xi = 4i+j), G rows
+      // (1,0,0), (.5,.5,.5), (.5,-.5,.5), (0,0,1); the data gradient uses the stencil rotated by pi
+      const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
+      if (ok) {
+        const float* src = transpose ? w + rr * co_stride + c * ci_stride
+                                     : w + c * co_stride + rr * ci_stride;
+        float g[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k] = src[tap_base + (transpose ? 8 - k : k) * tap_step];
+        const int i = tap >> 2, j = tap & 3;
+        float col[3];   // (G g)[i][b]
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const float g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
+          col[b] = i == 0 ? g0 : i == 1 ? 0.5f * ((g0 + g1) + g2) : i == 2 ? 0.5f * ((g0 - g1) + g2) : g2;
+        }
+        v = j == 0 ? col[0] : j == 1 ? 0.5f * ((col[0] + col[1]) + col[2])
+                            : j == 2 ? 0.5f * ((col[0] - col[1]) + col[2]) : col[2];
+      }
+    } else if (wino) {
       // 4 transformed matrices of a 3-tap temporal stencil (taps == 4 here): G0 = w0,
       // G1 = (w0+w1+w2)/2, G2 = (w0-w1+w2)/2, G3 = w2; the data gradient uses the flipped stencil
       const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
@@ -1070,7 +1516,7 @@ int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   constexpr int TAPS = KT * KH * KW;
   if (p.plane > PCH * 64) return COCLR_EINVAL;
   a.mtiles = cdiv(a.Cout, BM);
-  a.planeS = cdiv(p.plane, 64) * 64;
+  a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;    // 16-byte staging packs rows back to back
   a.nchunks = cdiv(a.Cin, CC);
   const size_t stage = ((size_t)TAPS * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
   const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
@@ -1143,9 +1589,11 @@ extern "C" int coclr_conv_pack_weights(const float* w, float* packed, int cout, 
                                        int64_t co_stride, int64_t ci_stride, int tap_base,
                                        int tap_step, int transpose, int row0, int rows_total,
                                        int col0, int cols_total, void* stream) {
-  const int wino = (transpose >> 1) & 1;       // bit 1: temporal Winograd operand (taps must be 4)
+  // bit 1: Winograd operand -- taps = 4: F(2,3) of a 3-tap temporal stencil, taps = 16:
+  // F(2x2,3x3) of a 9-tap spatial stencil
+  const int wino = (transpose >> 1) & 1;
   transpose &= 1;
-  if (wino && taps != 4) return COCLR_EINVAL;
+  if (wino && taps != 4 && taps != 16) return COCLR_EINVAL;
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
   const bool placed = rows_total > 0 && cols_total > 0;
   if (placed && (row0 < 0 || col0 < 0 || row0 + r > rows_total || col0 + c > cols_total))
@@ -1181,6 +1629,17 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
       if (p->plane > 256) return COCLR_EINVAL;
       *variant = 3;
     }
+  } else if (kt == 1 && kh == 3 && kw == 3 && d->algo == 1) {
+    // Winograd F(2x2,3x3): plan over 2x2 output blocks as a (1,4,4) stencil with stride (1,2,2)
+    if (!(p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 0 && p->ph == 1 && p->pw == 1 &&
+          p->dt == 1 && p->dh == 1 && p->dw == 1 && p->Hi == p->Ho && p->Wi == p->Wo &&
+          p->Ti == p->To && (p->Ho % 2) == 0 && (p->Wo % 2) == 0 && d->ys_t == 0))
+      return COCLR_EINVAL;
+    p->Ho /= 2; p->Wo /= 2;
+    p->sh = p->sw = 2;
+    conv_pick_box(p, 6, 1, 4, 4);
+    if (p->plane > 640) return COCLR_EINVAL;
+    *variant = 60;
   } else if (kt == 1 && kh == 3 && kw == 3) {
     c = choose_tile(*p, 1, 3, 3, true, true, 256, 512);
     conv_pick_box(p, c.lbn, 1, 3, 3);
@@ -1277,12 +1736,11 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
   if (((double)(1 << p.lTN) * (double)a.y_nstride + (double)(a.Cout + 128) * a.y_cstride) * 4.0 >= lim)
     return COCLR_EINVAL;
   if ((double)d->kt * d->kh * d->kw * a.CinP * a.CoutP * 4.0 >= lim) return COCLR_EINVAL;
-  // pointwise with the box a contiguous, 16-byte aligned run of exactly BN positions:
-  // 16-byte LDS-DMA for the input too
-  const int bn_v = variant == 2 ? 64 : 128;
-  const bool xv4 = variant <= 2 && p.Hi == 1 && p.Ti == 1 && p.lTH == 0 && p.lTT == 0 && p.lTW >= 2 &&
-                   p.plane == bn_v && (p.Wi % 4) == 0 && (a.x_cstride % 4) == 0 &&
-                   (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0;
+  // stencils with no reach along the flattened (H,W) axis, everything 16-byte aligned:
+  // 16-byte LDS-DMA for the input window too
+  const bool xv4 = d->kh == 1 && d->kw == 1 && p.Hi == 1 && p.WH == 1 && p.sw == 1 && p.lTW >= 2 &&
+                   p.dt == 1 && p.dh == 1 && p.dw == 1 && (p.Wi % 4) == 0 && (p.plane % 4) == 0 &&
+                   (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0;
   switch (variant) {
     case 0:  return xv4 ? launch_variant<1, 1, 1, 32, 128, 128, 2, true>(a, p, stream)
                         : launch_variant<1, 1, 1, 32, 128, 128, 2>(a, p, stream);
@@ -1295,10 +1753,14 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
     case 11: return launch_variant<1, 3, 3, 8, 64, 128, 4>(a, p, stream);
     case 12: return launch_variant<1, 3, 3, 8, 64, 64, 4>(a, p, stream);
     case 13: return launch_variant<1, 3, 3, 8, 64, 64, 8>(a, p, stream);
-    case 20: return launch_variant<3, 1, 1, 4, 128, 128, 4>(a, p, stream);
-    case 21: return launch_variant<3, 1, 1, 8, 64, 128, 4>(a, p, stream);
-    case 22: return launch_variant<3, 1, 1, 8, 64, 64, 4>(a, p, stream);
-    case 25: return launch_variant<4, 1, 1, 8, 64, 128, 4>(a, p, stream);
+    case 20: return xv4 ? launch_variant<3, 1, 1, 4, 128, 128, 4, true>(a, p, stream)
+                        : launch_variant<3, 1, 1, 4, 128, 128, 4>(a, p, stream);
+    case 21: return xv4 ? launch_variant<3, 1, 1, 8, 64, 128, 4, true>(a, p, stream)
+                        : launch_variant<3, 1, 1, 8, 64, 128, 4>(a, p, stream);
+    case 22: return xv4 ? launch_variant<3, 1, 1, 8, 64, 64, 4, true>(a, p, stream)
+                        : launch_variant<3, 1, 1, 8, 64, 64, 4>(a, p, stream);
+    case 25: return xv4 ? launch_variant<4, 1, 1, 8, 64, 128, 4, true>(a, p, stream)
+                        : launch_variant<4, 1, 1, 8, 64, 128, 4>(a, p, stream);
     case 50: {
       // a.To = frame pairs; the kernel finds the frame count in yst and the plane pitch in yHf/yWf
       a.yst = d->To; a.yHf = p.Ho; a.yWf = p.Wo;
@@ -1310,9 +1772,20 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
       return xv4 ? launch_wino_t<16, 64, 64, 4, true>(a, p, stream)
                  : launch_wino_t<16, 64, 64, 4, false>(a, p, stream);
     }
+    case 60: {
+      // a.Ho/Wo = 2x2 blocks; the destination keeps its full row pitch
+      if (n_index || ((uintptr_t)y % 8) != 0 || (a.y_nstride % 2) != 0) return COCLR_EINVAL;
+      a.yHf = d->Ho; a.yWf = d->Wo;
+      a.y_cstride = d->To * d->Ho * d->Wo;
+      if ((((double)(1 << p.lTN)) * (double)a.y_nstride + (double)(a.Cout + 128) * a.y_cstride) * 4.0 >= lim)
+        return COCLR_EINVAL;
+      if (16.0 * a.CinP * a.CoutP * 4.0 >= lim) return COCLR_EINVAL;
+      return launch_wino_hw<8, 10>(a, p, stream);
+    }
     case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);
     case 31: return launch_stem<7, 7, 3, 20>(a, p, stream);
-    case 40: return launch_variant<7, 1, 1, 8, 64, 128, 8>(a, p, stream);
+    case 40: return xv4 ? launch_variant<7, 1, 1, 8, 64, 128, 8, true>(a, p, stream)
+                        : launch_variant<7, 1, 1, 8, 64, 128, 8>(a, p, stream);
   }
   return COCLR_EINVAL;
 }

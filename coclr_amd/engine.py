@@ -230,12 +230,15 @@ class Run:
     def pack(self, w, transpose, kt_slice=None, taps=None, tap_base=0, tap_step=1, algo=0):
         """[Cout][Cin][taps] -> [taps][Cin'][Cout'] (or the dgrad operand).  kt_slice picks
         one temporal slice of the stencil; (taps, tap_base, tap_step) an arithmetic subset;
-        algo=1 the four Winograd F(2,3) matrices of a (3,1,1) stencil."""
+        algo=1 the Winograd-domain matrices of a (3,1,1) or (1,3,3) stencil."""
         cout, cin, kt, kh, kw = w.shape
         if algo == 1:
-            n = ops.conv_packed_size(cin, cout, 4, transpose)
+            # (3,1,1): 4 matrices of F(2,3); (1,3,3): 16 matrices of F(2x2,3x3)
+            vt = 4 if kt == 3 else 16
+            n = ops.conv_packed_size(cin, cout, vt, transpose)
             packed = self._packed_buffer(w, ("wino", bool(transpose)), n, False)
-            ops.conv_pack_weights(w, packed, cout, cin, 4, cin * 3, 3, 0, int(bool(transpose)) | 2, 1)
+            ops.conv_pack_weights(w, packed, cout, cin, vt, cin * kt * kh * kw, kt * kh * kw, 0,
+                                  int(bool(transpose)) | 2, 1)
             return packed
         if taps is not None:
             base = tap_base
@@ -326,6 +329,8 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
         geoms = _sliced_geoms(N, Cin, Cout, idim, k, s, p)
     else:
         geoms = [ops.conv_geom(N, Cin, Cout, idim, k, s, p)]
+        if n_index is not None and geoms[0].algo and k[1] > 1:
+            geoms = [ops.ConvGeom(N, Cin, Cout, idim, k, s, p)]    # the gather lives in the direct kernel
     odim = geoms[0].odim
     want_y = training or run.save or residual is not None
 

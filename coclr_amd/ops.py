@@ -51,15 +51,26 @@ def _chk5(t, name):
 
 
 WINOGRAD = os.environ.get("COCLR_WINOGRAD", "1") != "0"
+WINOGRAD_HW = os.environ.get("COCLR_WINOGRAD_HW", "1") != "0"
 
 
-def winograd_ok(cin, k, s, p, d, lattice):
-    """(3,1,1) stride-1 pad-1 convolutions (the temporal half of every STConv3d,
-    backbone/s3dg.py:41) can run as Winograd F(2,3) along T: 4 channel contractions per pair of
-    output frames instead of 6.  Narrow layers stay direct (the kernel stages 16 channels at a
-    time)."""
-    return (WINOGRAD and tuple(k) == (3, 1, 1) and tuple(s) == (1, 1, 1) and tuple(p) == (1, 0, 0)
-            and tuple(d) == (1, 1, 1) and lattice is None and cin >= 16)
+def winograd_ok(cin, k, s, p, d, lattice, odim=None):
+    """Stride-1 'same' convolutions of S3D's separable units (backbone/s3dg.py:39-42) can run as
+    Winograd (algo = 1):
+      * (3,1,1), pad (1,0,0): F(2,3) along T -- 4 channel contractions per pair of output frames
+        instead of 6;
+      * (1,3,3), pad (0,1,1), even H and W >= 4: F(2x2,3x3) -- 16 contractions per 2x2 output block
+        instead of 36.
+    Narrow layers stay direct (the kernels stage 8-16 channels at a time)."""
+    if not (WINOGRAD and tuple(s) == (1, 1, 1) and tuple(d) == (1, 1, 1) and lattice is None):
+        return False
+    k, p = tuple(k), tuple(p)
+    if k == (3, 1, 1):
+        return p == (1, 0, 0) and cin >= 16
+    if k == (1, 3, 3):
+        return (WINOGRAD_HW and p == (0, 1, 1) and cin >= 16 and odim is not None
+                and odim[1] % 2 == 0 and odim[2] % 2 == 0 and odim[1] >= 4 and odim[2] >= 4)
+    return False
 
 
 class ConvGeom:
@@ -84,10 +95,11 @@ class ConvGeom:
         self.lattice = lattice
         lat = (0,) * 9 if lattice is None else tuple(lattice[0]) + tuple(lattice[1]) + \
             tuple(lattice[2])
-        # algo 1 = Winograd F(2,3) along T (see winograd_ok); the packed operand differs
+        # algo 1 = Winograd (see winograd_ok); the packed operand differs
         self.algo = int(algo)
-        if self.algo == 1 and not winograd_ok(self.Cin, self.k, self.s, self.p, self.d, lattice):
-            raise ValueError("coclr_amd: temporal Winograd needs a (3,1,1) stride-1 pad-1 stencil")
+        if self.algo == 1 and not winograd_ok(self.Cin, self.k, self.s, self.p, self.d, lattice,
+                                              self.odim):
+            raise ValueError("coclr_amd: Winograd needs a (3,1,1) or (1,3,3) stride-1 'same' stencil")
         self.desc = ConvDesc(self.N, self.Cin, self.Cout, *self.idim, *self.odim, *self.k,
                              *self.s, *self.p, *self.d, 0, 0, *lat, 0, self.algo)
         self._cache = {}
@@ -105,7 +117,7 @@ class ConvGeom:
             if min(pad) < 0:
                 raise ValueError("coclr_amd: padding larger than kernel-1 is not supported")
             algo = 1 if self.algo == 1 and winograd_ok(self.Cout, self.k, (1, 1, 1), pad, self.s,
-                                                       None) else 0
+                                                       None, self.idim) else 0
             g = ConvGeom(self.N, self.Cout, self.Cin, self.odim, self.k, (1, 1, 1), pad,
                          d=self.s, odim=self.idim, algo=algo)
             self._cache["dgrad"] = g
@@ -178,8 +190,10 @@ def conv_geom(N, Cin, Cout, idim, k, s, p):
     if g is None:
         if len(_GEOMS) > 8192:
             _GEOMS.clear()
-        algo = 1 if winograd_ok(Cin, k, s, p, (1, 1, 1), None) else 0
-        g = _GEOMS[key] = ConvGeom(N, Cin, Cout, idim, k, s, p, algo=algo)
+        g = ConvGeom(N, Cin, Cout, idim, k, s, p)
+        if winograd_ok(Cin, k, s, p, (1, 1, 1), None, g.odim):
+            g = ConvGeom(N, Cin, Cout, idim, k, s, p, algo=1)
+        _GEOMS[key] = g
     return g
 
 

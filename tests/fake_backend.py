@@ -31,14 +31,14 @@ def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base
     wino = bool(int(transpose) & 2)
     transpose = bool(int(transpose) & 1)
     if wino:
-        # the double keeps the plain 3-tap stencil in the first three slots of the 4-slot operand
-        taps_src = 3
-        w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, 3), (co_stride, ci_stride, 1), 0)
+        # the double keeps the plain stencil (3 or 9 taps) in the first slots of the 4 / 16-slot operand
+        real = 3 if taps == 4 else 9
+        w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, real), (co_stride, ci_stride, 1), 0)
         r, c = (cout, cin) if transpose else (cin, cout)
-        dst = packed.view(4, _r32(r), _r128(c))
+        dst = packed.view(taps, _r32(r), _r128(c))
         dst.zero_()
         src = w3.flip(2).permute(2, 0, 1) if transpose else w3.permute(2, 1, 0)
-        dst[:3, :r, :c] = src
+        dst[:real, :r, :c] = src
         return
     w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, taps),
                           (co_stride, ci_stride, tap_step), tap_base)
@@ -54,7 +54,8 @@ def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base
 def _unpack(geom, wp):
     taps = geom.taps
     if getattr(geom, "algo", 0) == 1:
-        w = wp.view(4, _r32(geom.Cin), _r128(geom.Cout))[:3, :geom.Cin, :geom.Cout]
+        slots = 4 if taps == 3 else 16
+        w = wp.view(slots, _r32(geom.Cin), _r128(geom.Cout))[:taps, :geom.Cin, :geom.Cout]
         return w.permute(2, 1, 0).reshape(geom.Cout, geom.Cin, *geom.k).contiguous()
     w = wp.view(taps, _r32(geom.Cin), _r128(geom.Cout))[:, :geom.Cin, :geom.Cout]
     return w.permute(2, 1, 0).reshape(geom.Cout, geom.Cin, *geom.k).contiguous()

@@ -493,3 +493,51 @@ def test_conv_temporal_winograd(case):
     dg = g.dgrad()
     ops.conv_fwd(dg, dyd, run.pack(wd, True, algo=1), dx)
     close(dx, x.grad, what="winograd dgrad")
+
+
+WINO_HW_CASES = [(2, 64, 192, (2, 32, 32)), (2, 192, 208, (4, 16, 16)), (3, 48, 96, (3, 8, 8)),
+                 (2, 32, 24, (5, 4, 4)), (2, 16, 48, (1, 6, 10)), (5, 160, 320, (2, 8, 8)),
+                 (2, 24, 64, (2, 12, 20)), (9, 40, 64, (3, 4, 4))]
+
+
+@pytest.mark.parametrize("case", WINO_HW_CASES, ids=lambda c: "%d_%d_%d_%s" % c)
+def test_conv_spatial_winograd(case):
+    """(1,3,3) stride-1 pad-1 convolutions through Winograd F(2x2,3x3) (algo = 1): forward with
+    BatchNorm partial sums, accumulate form, fused affine+ReLU epilogue, and the data gradient --
+    ragged channel counts, maps that are not a power of two, boxes spanning frames and samples."""
+    from coclr_amd import ops, engine
+    N, Cin, Cout, dims = case
+    k, s, p = (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    torch.manual_seed(7)
+    x = torch.randn(N, Cin, *dims, requires_grad=True)
+    w = (torch.randn(Cout, Cin, *k) * 0.05).requires_grad_(True)
+    ref = F.conv3d(x, w, None, s, p)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    g = ops.conv_geom(N, Cin, Cout, dims, k, s, p)
+    assert g.algo == 1 and g.dgrad().algo == 1
+    run = engine.Run(torch.device("cuda"), save=False)
+    wd, xd, dyd = dev(w.detach()), dev(x.detach()), dev(dy)
+    y = torch.full((N, Cout, *g.odim), float("nan"), device="cuda")
+    stats = torch.empty(2 * Cout * g.ntiles(), device="cuda")
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, stats=stats)
+    close(y, ref, what="winograd fwd")
+    st = stats.view(2, Cout, -1).double().sum(-1).cpu()
+    close(st[0], ref.double().sum((0, 2, 3, 4)), rtol=1e-3, what="stats sum")
+    close(st[1], (ref.double() ** 2).sum((0, 2, 3, 4)), what="stats sumsq")
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, accumulate=True)
+    close(y, 2 * ref, what="winograd accumulate")
+    sc, sf = torch.rand(Cout) + 0.5, torch.randn(Cout)
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, ep_scale=dev(sc), ep_shift=dev(sf), relu=True)
+    close(y, torch.relu(ref * sc[None, :, None, None, None] + sf[None, :, None, None, None]),
+          what="winograd affine+relu epilogue")
+    dx = torch.full((N, Cin, *dims), float("nan"), device="cuda")
+    dg = g.dgrad()
+    ops.conv_fwd(dg, dyd, run.pack(wd, True, algo=1), dx)
+    close(dx, x.grad, what="winograd dgrad")
+    # a channel slice of a wider destination (concat-free inception output)
+    wide = torch.zeros(N, Cout + 8, *g.odim, device="cuda")
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), wide[:, 8:])
+    close(wide[:, 8:], ref, what="winograd into a channel slice")
+    assert float(wide[:, :8].abs().max()) == 0.0
+
