@@ -250,7 +250,7 @@ def main():
         kms = timer.mean_ms()
         flops = 2.0 * B * 192 * 64 * 9 * tq * hq * hq          # algorithmic, per launch
         wino = bool(iso_ms) and iso_algo == 1
-        kname = ("conv_wino_hw_kernel<8,10> Winograd F(2x2,3x3)" if wino
+        kname = ("conv_wino_hw_kernel<8,6> Winograd F(2x2,3x3)" if wino
                  else "conv_igemm_kernel<1,3,3,8,64,128,4>")
         roof = None
         traffic = None

@@ -729,6 +729,7 @@ int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
 // ds_read_b64 and transformed in registers under the MFMAs of the previous step; the epilogue
 // applies A^T . A and stores row pairs as 8-byte buffer stores.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One element of an accumulator set, read where the program says so: left to itself the
 // compiler copies whole 16-register sets out of the AGPRs, 256 VGPRs at the epilogue's peak.
@@ -754,7 +755,11 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   extern __shared__ __align__(16) float smem[];
   const int planeS = a.planeS;
   const int stage_floats = W_FLOATS + CC * planeS;
-  float* red = smem + 2 * stage_floats;     // [4][BM][2] statistics scratch, never DMA'd over
+  // after the two stages, never DMA'd over: per-lane statistics partials [2][BM][64] and the window
+  // coordinate table [PCH][256]
+  float* redS = smem + 2 * stage_floats;
+  float* redQ = redS + BM * 64;
+  unsigned* wtab = reinterpret_cast<unsigned*>(redQ + BM * 64);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -776,11 +781,10 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   int tile = (nwg % 8 == 0) ? ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
   if (tile >= total_tiles) return;
 
-  const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
+  const unsigned wvoff = (unsigned)lane * 16u;
 
   // tile-independent half of the window gather: the window coordinates (n, t, h, w) of the
   // elements this lane fetches, packed one byte each, parked in LDS
-  unsigned* wtab = reinterpret_cast<unsigned*>(red + 4 * BM * 2);     // [PCH][256]
   {
     const int hw = a.WH * WW;
 #pragma unroll
@@ -810,7 +814,10 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
     ptn = p >> (a.lTW + a.lTH + a.lTT);
     lanebase = W_FLOATS + ptn * a.plane1 + (ptt * a.WH + pth * 2) * WW + ptw * 2 + half * planeS;
   }
-  const int abase = half * BM + wm * 32 + l31;
+  // weights in LDS: [c][m][16 xi]; the four xi quads of row m sit rotated by m>>2, so the 16-byte
+  // reads of 16 neighbouring rows fall on 16 different bank groups
+  const int abase = (half * BM + wm * 32 + l31) * 16;
+  const int arot = (l31 >> 2) & 3;
   const __amdgpu_buffer_rsrc_t rw =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
 
@@ -844,12 +851,20 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
                                            0x00020000);
   };
 
+  // DMA of one chunk into stage `sbase`.  Weights: the packed operand is [cin][cout][16 xi], so a
+  // channel row of the 64-cout tile is 4 KiB = four 1 KiB pieces, copied verbatim.
   auto stage = [&](int cin0, float* sbase) {
-    for (int p = wave; p < WPIECES; p += 4) {
-      const int row0 = p * RPP;
-      const int tap = row0 / CC, c0 = row0 % CC;
-      const unsigned soff = (unsigned)((((long)tap * a.CinP + cin0 + c0) * a.CoutP + cout0) * 4);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sbase + p * 256), 16, wvoff, soff, 0, 0);
+    {
+      // piece p = wave + 4k is quarter `wave` of channel row k: both offsets advance by constants
+      unsigned soff = (unsigned)((((long)cin0 * a.CoutP + cout0) * 16 + wave * 256) * 4);
+      const unsigned sstep = (unsigned)a.CoutP * 64u;
+      float* dst = sbase + wave * 256;
+#pragma unroll
+      for (int k = 0; k < WPIECES / 4; ++k) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(dst), 16, wvoff, soff, 0, 0);
+        soff += sstep;
+        dst += 1024;
+      }
     }
     float* xs = sbase + W_FLOATS;
 #pragma unroll
@@ -919,67 +934,68 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
         if (ch == 1 || nchunks == 1) { flush(std::integral_constant<int, 8>{}); pending = false; }
       }
 
-      // step q: channel pair (2q, 2q+1).  Two-deep software pipeline: while the 16 MFMAs of
-      // step q issue, the weights of step q+1 and the patch of step q+2 are fetched from LDS and
-      // the patch of step q+1 is transformed.
-      auto fetch_a = [&](int q, float (&av)[16]) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) av[t] = cur[abase + (t * CC + 2 * q) * BM];
+      // step q: channel pair (2q, 2q+1).  Software pipeline with every buffer single except V:
+      // while the 16 MFMAs of step q issue, the patch of step q+1 (already in dv) is transformed
+      // into V[(q+1)&1], the patch of step q+2 is fetched into dv, and each weight quad of av is
+      // refilled for step q+1 as soon as its four MFMAs have gone.
+      auto fetch_a_quad = [&](int q, int g, float (&av)[16]) {
+        const float4 v = *reinterpret_cast<const float4*>(
+            &cur[abase + 2 * q * BM * 16 + ((g + arot) & 3) * 4]);
+        av[4 * g + 0] = v.x; av[4 * g + 1] = v.y; av[4 * g + 2] = v.z; av[4 * g + 3] = v.w;
       };
-      auto fetch_d = [&](int q, float (&dv)[16]) {
+      // patch rows as two column pairs (the ds_read_b64 granules): the row pass of B^T d B is then
+      // elementwise on pairs, the column pass plain scalar ops on their halves
+      auto fetch_d = [&](int q, f32x2 (&dv)[8]) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const float* src = &cur[lanebase + rr * WW + 2 * q * planeS];
-          const float2 lo = *reinterpret_cast<const float2*>(src);
-          const float2 hi = *reinterpret_cast<const float2*>(src + 2);
-          dv[rr * 4 + 0] = lo.x; dv[rr * 4 + 1] = lo.y; dv[rr * 4 + 2] = hi.x; dv[rr * 4 + 3] = hi.y;
+          dv[2 * rr] = *reinterpret_cast<const f32x2*>(src);
+          dv[2 * rr + 1] = *reinterpret_cast<const f32x2*>(src + 2);
         }
       };
-      auto transform = [&](const float (&dv)[16], float (&V)[16]) {
-        float t_[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          t_[0 + j] = dv[0 + j] - dv[8 + j];
-          t_[4 + j] = dv[4 + j] + dv[8 + j];
-          t_[8 + j] = dv[8 + j] - dv[4 + j];
-          t_[12 + j] = dv[4 + j] - dv[12 + j];
-        }
+      auto transform = [&](const f32x2 (&dv)[8], float (&V)[16]) {
+        f32x2 tl[4], th[4];
+        tl[0] = dv[0] - dv[4]; th[0] = dv[1] - dv[5];
+        tl[1] = dv[2] + dv[4]; th[1] = dv[3] + dv[5];
+        tl[2] = dv[4] - dv[2]; th[2] = dv[5] - dv[3];
+        tl[3] = dv[2] - dv[6]; th[3] = dv[3] - dv[7];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          V[4 * i + 0] = t_[4 * i + 0] - t_[4 * i + 2];
-          V[4 * i + 1] = t_[4 * i + 1] + t_[4 * i + 2];
-          V[4 * i + 2] = t_[4 * i + 2] - t_[4 * i + 1];
-          V[4 * i + 3] = t_[4 * i + 1] - t_[4 * i + 3];
+          V[4 * i + 0] = tl[i].x - th[i].x;
+          V[4 * i + 1] = tl[i].y + th[i].x;
+          V[4 * i + 2] = th[i].x - tl[i].y;
+          V[4 * i + 3] = tl[i].y - th[i].y;
         }
       };
-      float av[2][16], V[2][16], dv[2][16];
-      fetch_d(0, dv[0]);
-      fetch_a(0, av[0]);
-      if (QS > 1) fetch_d(1, dv[1]);
-      transform(dv[0], V[0]);
+      float av[16], V[2][16];
+      f32x2 dv[8];
+      fetch_d(0, dv);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fetch_a_quad(0, g, av);
+      transform(dv, V[0]);
+      if (QS > 1) fetch_d(1, dv);
 #pragma unroll
       for (int q = 0; q < QS; ++q) {
         __builtin_amdgcn_sched_barrier(0);
-        if (q + 1 < QS) fetch_a(q + 1, av[(q + 1) & 1]);
-        if (q + 2 < QS) fetch_d(q + 2, dv[q & 1]);
-        if (q + 1 < QS) transform(dv[(q + 1) & 1], V[(q + 1) & 1]);
+        if (q + 1 < QS) transform(dv, V[(q + 1) & 1]);
+        if (q + 2 < QS) fetch_d(q + 2, dv);
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t], V[q & 1][t], acc[t], 0, 0, 0);
-        // issue order: one MFMA, two LDS reads, two VALU ops of the transform
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            acc[4 * g + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * g + k], V[q & 1][4 * g + k],
+                                                                 acc[4 * g + k], 0, 0, 0);
+          if (q + 1 < QS) fetch_a_quad(q + 1, g, av);
+        }
+        // issue order: one MFMA, two VALU ops of the transform, an LDS read when one is ready
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if (pending) {   // unreachable unless nchunks == 0
-      flush(std::integral_constant<int, 0>{});
-      flush(std::integral_constant<int, 8>{});
-      pending = false;
     }
 
     // ---- epilogue: Y = A^T M A into registers; hand the LDS stream to the next tile ---------
@@ -1040,13 +1056,8 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
             s = (v00 + v01) + (v10 + v11);
             ss = (v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11);
           }
-          s = row16_sum(s);
-          ss = row16_sum(ss);
-          if ((lane & 15) == 0) {
-            const int slot = wn * 2 + (l31 >> 4);
-            red[(slot * BM + ml) * 2 + 0] = s;
-            red[(slot * BM + ml) * 2 + 1] = ss;
-          }
+          redS[ml * 64 + wn * 32 + l31] = s;      // one partial per block position, summed below
+          redQ[ml * 64 + wn * 32 + l31] = ss;
         }
         if (MODE == 2) {
           const int co = e_cout0 + ml;
@@ -1076,18 +1087,24 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
 
     if (want_stats) {
       __syncthreads();
-      if (tid < BM) {
-        const int co = e_cout0 + tid;
-        if (co < a.Cout) {
-          float s = 0.f, ss = 0.f;
+      // thread t: row t>>2, quarter t&3 of its 64 partials; the quarters meet through DPP
+      const int row = tid >> 2, qtr = tid & 3;
+      float s = 0.f, ss = 0.f;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            s += red[(k * BM + tid) * 2];
-            ss += red[(k * BM + tid) * 2 + 1];
-          }
-          a.stats[(long)co * a.ntiles + e_ntile] = s;
-          a.stats[((long)a.Cout + co) * a.ntiles + e_ntile] = ss;
-        }
+      for (int k = 0; k < 4; ++k) {
+        const float4 ps = *reinterpret_cast<const float4*>(&redS[row * 64 + qtr * 16 + 4 * k]);
+        const float4 pq = *reinterpret_cast<const float4*>(&redQ[row * 64 + qtr * 16 + 4 * k]);
+        s += (ps.x + ps.y) + (ps.z + ps.w);
+        ss += (pq.x + pq.y) + (pq.z + pq.w);
+      }
+      s += __builtin_amdgcn_update_dpp(0.f, s, 0xB1, 0xf, 0xf, true);
+      s += __builtin_amdgcn_update_dpp(0.f, s, 0x4E, 0xf, 0xf, true);
+      ss += __builtin_amdgcn_update_dpp(0.f, ss, 0xB1, 0xf, 0xf, true);
+      ss += __builtin_amdgcn_update_dpp(0.f, ss, 0x4E, 0xf, 0xf, true);
+      const int co = e_cout0 + row;
+      if (qtr == 0 && co < a.Cout) {
+        a.stats[(long)co * a.ntiles + e_ntile] = s;
+        a.stats[((long)a.Cout + co) * a.ntiles + e_ntile] = ss;
       }
     }
     if (!more) break;
@@ -1104,8 +1121,8 @@ int launch_wino_hw(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   a.planeS = cdiv(p.plane, 64) * 64;
   a.nchunks = cdiv(a.Cin, CC);
   const size_t stage = ((size_t)16 * CC * 64 + (size_t)CC * a.planeS) * sizeof(float);
-  // two stages + statistics scratch + window coordinate table
-  const size_t lds = 2 * stage + (size_t)4 * 64 * 2 * sizeof(float) + (size_t)PCH * 256 * sizeof(unsigned);
+  // two stages + statistics partials + window coordinate table
+  const size_t lds = 2 * stage + (size_t)2 * 64 * 64 * sizeof(float) + (size_t)PCH * 256 * sizeof(unsigned);
   if (lds > 160 * 1024) return COCLR_EINVAL;
   auto kern = conv_wino_hw_kernel<CC, PCH>;
   static bool attr_done = false;
@@ -1505,7 +1522,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
       if (rr < Cout && c < Cin)
         v = w[rr * co_stride + c * ci_stride + tap_base + (taps - 1 - tap) * tap_step];
     }
-    dst[((long)tap * RP + row0 + rr) * CP + col0 + c] = v;
+    if (wino && taps == 16)
+      // F(2x2,3x3) operand: [r][c][16 xi], the xi quads of column c rotated by c>>2 (the kernel's
+      // 16-byte LDS reads of neighbouring columns then hit different bank groups)
+      dst[((long)(row0 + rr) * CP + col0 + c) * 16 + ((((tap >> 2) + (c >> 2)) & 3) << 2) + (tap & 3)] = v;
+    else
+      dst[((long)tap * RP + row0 + rr) * CP + col0 + c] = v;
   }
 }
 
@@ -1594,6 +1616,7 @@ extern "C" int coclr_conv_pack_weights(const float* w, float* packed, int cout, 
   const int wino = (transpose >> 1) & 1;
   transpose &= 1;
   if (wino && taps != 4 && taps != 16) return COCLR_EINVAL;
+  if (wino && taps == 16 && rows_total > 0 && cols_total > 0) return COCLR_EINVAL;   // stand-alone only
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
   const bool placed = rows_total > 0 && cols_total > 0;
   if (placed && (row0 < 0 || col0 < 0 || row0 + r > rows_total || col0 + c > cols_total))
@@ -1780,7 +1803,7 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
       if ((((double)(1 << p.lTN)) * (double)a.y_nstride + (double)(a.Cout + 128) * a.y_cstride) * 4.0 >= lim)
         return COCLR_EINVAL;
       if (16.0 * a.CinP * a.CoutP * 4.0 >= lim) return COCLR_EINVAL;
-      return launch_wino_hw<8, 10>(a, p, stream);
+      return p.plane <= 384 ? launch_wino_hw<8, 6>(a, p, stream) : launch_wino_hw<8, 10>(a, p, stream);
     }
     case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);
     case 31: return launch_stem<7, 7, 3, 20>(a, p, stream);

@@ -55,8 +55,8 @@ WINOGRAD_HW = os.environ.get("COCLR_WINOGRAD_HW", "1") != "0"
 
 
 def winograd_ok(cin, k, s, p, d, lattice, odim=None):
-    """Stride-1 'same' convolutions of S3D's separable units (backbone/s3dg.py:39-42) can run as
-    Winograd (algo = 1):
+    """Can this convolution run through the Winograd kernels (algo = 1)?  Stride-1 'same'
+    convolutions of S3D's separable units (backbone/s3dg.py:39-42):
       * (3,1,1), pad (1,0,0): F(2,3) along T -- 4 channel contractions per pair of output frames
         instead of 6;
       * (1,3,3), pad (0,1,1), even H and W >= 4: F(2x2,3x3) -- 16 contractions per 2x2 output block
@@ -71,6 +71,15 @@ def winograd_ok(cin, k, s, p, d, lattice, odim=None):
         return (WINOGRAD_HW and p == (0, 1, 1) and cin >= 16 and odim is not None
                 and odim[1] % 2 == 0 and odim[2] % 2 == 0 and odim[1] >= 4 and odim[2] >= 4)
     return False
+
+
+def winograd_pays(cin, k, s, p, odim):
+    """Policy of conv_geom(): use Winograd where it is measurably faster.  The F(2x2,3x3) kernel
+    holds one workgroup per CU; on 8x8 maps it only ties the direct kernel and on 4x4 maps it
+    loses (profiles/r01_g_layers.txt), so the spatial form is kept for maps of 16x16 and up."""
+    if not winograd_ok(cin, k, s, p, (1, 1, 1), None, odim):
+        return False
+    return tuple(k) != (1, 3, 3) or (odim[1] >= 16 and odim[2] >= 16)
 
 
 class ConvGeom:
@@ -191,7 +200,7 @@ def conv_geom(N, Cin, Cout, idim, k, s, p):
         if len(_GEOMS) > 8192:
             _GEOMS.clear()
         g = ConvGeom(N, Cin, Cout, idim, k, s, p)
-        if winograd_ok(Cin, k, s, p, (1, 1, 1), None, g.odim):
+        if winograd_pays(Cin, k, s, p, g.odim):
             g = ConvGeom(N, Cin, Cout, idim, k, s, p, algo=1)
         _GEOMS[key] = g
     return g

@@ -53,9 +53,11 @@ typedef struct coclr_conv_desc {
   int32_t yo_t, yo_h, yo_w;
   int32_t yT, yH, yW;
   int32_t Nx;              /* samples addressable through n_index (0: N) */
-  int32_t algo;            /* 0: direct; 1: Winograd F(2,3) along T -- (3,1,1) stencil, stride 1,
-                              pad 1: w_packed must then be the 4-matrix operand made by
-                              coclr_conv_pack_weights(taps = 4, transpose | 2) */
+  int32_t algo;            /* 0: direct; 1: Winograd, w_packed must then be the transform-domain
+                              operand made by coclr_conv_pack_weights(transpose | 2):
+                              (3,1,1) stencil, stride 1, pad (1,0,0): F(2,3) along T, taps = 4;
+                              (1,3,3) stencil, stride 1, pad (0,1,1), even Ho/Wo >= 4, dense
+                              destination, no n_index: F(2x2,3x3), taps = 16 */
 } coclr_conv_desc;
 
 /* Number of fp32 elements of the packed-weight buffer for one conv. */
@@ -64,8 +66,10 @@ int coclr_conv_packed_size(int cin, int cout, int taps, int transpose, int64_t* 
 /* Re-lay [Cout][Cin][taps] weights as [taps][R'][C'] (zero padded: reduction
  * channels R to x32, produced channels C to x128).
  * transpose=0: operand of the forward conv (R = Cin, C = Cout); transpose=1: operand of
- * the data gradient (R = Cout, C = Cin, stencil flipped); transpose | 2 with taps = 4: the four
- * Winograd F(2,3) matrices of a 3-tap temporal stencil (coclr_conv_desc.algo = 1).  co/ci strides, tap_base and
+ * the data gradient (R = Cout, C = Cin, stencil flipped); transpose | 2: Winograd operand
+ * (coclr_conv_desc.algo = 1) -- taps = 4: the four F(2,3) matrices of a 3-tap temporal stencil,
+ * taps = 16: the sixteen F(2x2,3x3) matrices U = G g G^T of a 9-tap spatial stencil, laid out
+ * [R'][C'][16] (stand-alone operands only).  co/ci strides, tap_base and
  * tap_step address a sub-stencil: source tap of packed tap t is tap_base + t*tap_step
  * (one kt-slice of a (5,7,7) stem; the taps of one phase of a strided data gradient).
  * rows_total/cols_total > 0 place this tensor at (row0, col0) of a WIDER packed operand
