@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -35,6 +35,9 @@ _SIGNATURES = {
     "coclr_abi_version": [],
     "coclr_conv_packed_size": [i32, i32, i32, i32, _P(i64)],
     "coclr_conv_pack_weights": [vp, vp, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp],
+    "coclr_conv_pack_describe": [vp, vp, i32, i32, i32, i64, i64, i32, i32, i32, i32, i32, i32, i32,
+                                 _P(i64), _P(i32)],
+    "coclr_conv_pack_batch": [vp, vp, i32, vp],
     "coclr_conv3d_ntiles": [_P(ConvDesc), _P(i32)],
     "coclr_conv3d_fwd": [_P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "coclr_conv3d_wgrad_workspace": [_P(ConvDesc), _P(i64)],

@@ -1471,63 +1471,102 @@ int launch_stem(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
 // c < CP = produced channels), zero padded.
 //   forward : r = cin,  c = cout, src tap = tap_base + tap*tap_step
 //   dgrad   : r = cout, c = cin,  src tap = tap_base + (taps-1-tap)*tap_step (stencil flipped)
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst,
-                                    int Cout, int Cin, int taps, long co_stride, long ci_stride,
-                                    int tap_base, int tap_step, int RP, int CP, int transpose,
-                                    int row0, int col0, int rows, int cols, int wino) {
+struct PackDesc {
+  const float* w;
+  float* dst;
+  int Cout, Cin, taps;
+  long co_stride, ci_stride;
+  int tap_base, tap_step, RP, CP, transpose, row0, col0;
   // (rows, cols) = extent written per tap: the padded operand when it stands alone, only the
   // real sub-block when it is placed inside a wider (pre-zeroed) operand
-  const long total = (long)taps * rows * cols;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % cols);
-    const long q = e / cols;
-    const int rr = (int)(q % rows);
-    const int tap = (int)(q / rows);
-    float v = 0.f;
-    if (wino && taps == 16) {
-      // U = G g G^T of a 3x3 spatial stencil (16 transform-domain matrices, xi = 4i+j), G rows
-      // (1,0,0), (.5,.5,.5), (.5,-.5,.5), (0,0,1); the data gradient uses the stencil rotated by pi
-      const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
-      if (ok) {
-        const float* src = transpose ? w + rr * co_stride + c * ci_stride
-                                     : w + c * co_stride + rr * ci_stride;
-        float g[9];
+  int rows, cols, wino;
+};
+
+__device__ __forceinline__ void pack_element(const PackDesc& d, long e) {
+  const float* __restrict__ w = d.w;
+  const int Cout = d.Cout, Cin = d.Cin, taps = d.taps, transpose = d.transpose;
+  const long co_stride = d.co_stride, ci_stride = d.ci_stride;
+  const int tap_base = d.tap_base, tap_step = d.tap_step;
+  const int c = (int)(e % d.cols);
+  const long q = e / d.cols;
+  const int rr = (int)(q % d.rows);
+  const int tap = (int)(q / d.rows);
+  float v = 0.f;
+  if (d.wino && taps == 16) {
+    // U = G g G^T of a 3x3 spatial stencil (16 transform-domain matrices, xi = 4i+j), G rows
+    // (1,0,0), (.5,.5,.5), (.5,-.5,.5), (0,0,1); the data gradient uses the stencil rotated by pi
+    const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
+    if (ok) {
+      const float* src = transpose ? w + rr * co_stride + c * ci_stride
+                                   : w + c * co_stride + rr * ci_stride;
+      float g[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) g[k] = src[tap_base + (transpose ? 8 - k : k) * tap_step];
-        const int i = tap >> 2, j = tap & 3;
-        float col[3];   // (G g)[i][b]
+      for (int k = 0; k < 9; ++k) g[k] = src[tap_base + (transpose ? 8 - k : k) * tap_step];
+      const int i = tap >> 2, j = tap & 3;
+      float col[3];   // (G g)[i][b]
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const float g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
-          col[b] = i == 0 ? g0 : i == 1 ? 0.5f * ((g0 + g1) + g2) : i == 2 ? 0.5f * ((g0 - g1) + g2) : g2;
-        }
-        v = j == 0 ? col[0] : j == 1 ? 0.5f * ((col[0] + col[1]) + col[2])
-                            : j == 2 ? 0.5f * ((col[0] - col[1]) + col[2]) : col[2];
+      for (int b = 0; b < 3; ++b) {
+        const float g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
+        col[b] = i == 0 ? g0 : i == 1 ? 0.5f * ((g0 + g1) + g2) : i == 2 ? 0.5f * ((g0 - g1) + g2) : g2;
       }
-    } else if (wino) {
-      // 4 transformed matrices of a 3-tap temporal stencil (taps == 4 here): G0 = w0,
-      // G1 = (w0+w1+w2)/2, G2 = (w0-w1+w2)/2, G3 = w2; the data gradient uses the flipped stencil
-      const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
-      if (ok) {
-        const float* src = transpose ? w + rr * co_stride + c * ci_stride
-                                     : w + c * co_stride + rr * ci_stride;
-        float w0 = src[tap_base], w1 = src[tap_base + tap_step], w2 = src[tap_base + 2 * tap_step];
-        if (transpose) { const float t_ = w0; w0 = w2; w2 = t_; }
-        v = tap == 0 ? w0 : tap == 1 ? 0.5f * ((w0 + w1) + w2) : tap == 2 ? 0.5f * ((w0 - w1) + w2) : w2;
-      }
-    } else if (!transpose) {
-      if (rr < Cin && c < Cout) v = w[c * co_stride + rr * ci_stride + tap_base + tap * tap_step];
-    } else {
-      if (rr < Cout && c < Cin)
-        v = w[rr * co_stride + c * ci_stride + tap_base + (taps - 1 - tap) * tap_step];
+      v = j == 0 ? col[0] : j == 1 ? 0.5f * ((col[0] + col[1]) + col[2])
+                          : j == 2 ? 0.5f * ((col[0] - col[1]) + col[2]) : col[2];
     }
-    if (wino && taps == 16)
-      // F(2x2,3x3) operand: [r][c][16 xi], the xi quads of column c rotated by c>>2 (the kernel's
-      // 16-byte LDS reads of neighbouring columns then hit different bank groups)
-      dst[((long)(row0 + rr) * CP + col0 + c) * 16 + ((((tap >> 2) + (c >> 2)) & 3) << 2) + (tap & 3)] = v;
-    else
-      dst[((long)tap * RP + row0 + rr) * CP + col0 + c] = v;
+  } else if (d.wino) {
+    // 4 transformed matrices of a 3-tap temporal stencil (taps == 4 here): G0 = w0,
+    // G1 = (w0+w1+w2)/2, G2 = (w0-w1+w2)/2, G3 = w2; the data gradient uses the flipped stencil
+    const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
+    if (ok) {
+      const float* src = transpose ? w + rr * co_stride + c * ci_stride
+                                   : w + c * co_stride + rr * ci_stride;
+      float w0 = src[tap_base], w1 = src[tap_base + tap_step], w2 = src[tap_base + 2 * tap_step];
+      if (transpose) { const float t_ = w0; w0 = w2; w2 = t_; }
+      v = tap == 0 ? w0 : tap == 1 ? 0.5f * ((w0 + w1) + w2) : tap == 2 ? 0.5f * ((w0 - w1) + w2) : w2;
+    }
+  } else if (!transpose) {
+    if (rr < Cin && c < Cout) v = w[c * co_stride + rr * ci_stride + tap_base + tap * tap_step];
+  } else {
+    if (rr < Cout && c < Cin)
+      v = w[rr * co_stride + c * ci_stride + tap_base + (taps - 1 - tap) * tap_step];
+  }
+  if (d.wino && taps == 16)
+    // F(2x2,3x3) operand: [r][c][16 xi], the xi quads of column c rotated by c>>2 (the kernel's
+    // 16-byte LDS reads of neighbouring columns then hit different bank groups)
+    d.dst[((long)(d.row0 + rr) * d.CP + d.col0 + c) * 16 + ((((tap >> 2) + (c >> 2)) & 3) << 2) + (tap & 3)] = v;
+  else
+    d.dst[((long)tap * d.RP + d.row0 + rr) * d.CP + d.col0 + c] = v;
+}
+
+__global__ void pack_weights_kernel(const PackDesc d) {
+  const long total = (long)d.taps * d.rows * d.cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x)
+    pack_element(d, e);
+}
+
+// Every operand of an encoder in one launch: block b works on 1024 elements of table entry
+// blockmap[b][0] starting at element 1024 * blockmap[b][1].  The table rows are the 16 int64 that
+// coclr_conv_pack_describe writes.
+constexpr int kPackBlockElems = 1024;
+
+__global__ void __launch_bounds__(256)
+pack_weights_batch_kernel(const int64_t* __restrict__ table, const int32_t* __restrict__ blockmap) {
+  const int entry = blockmap[2 * blockIdx.x], local = blockmap[2 * blockIdx.x + 1];
+  const int64_t* t = table + (long)entry * 16;
+  PackDesc d;
+  d.w = reinterpret_cast<const float*>(t[0]);
+  d.dst = reinterpret_cast<float*>(t[1]);
+  d.Cout = (int)t[2]; d.Cin = (int)t[3]; d.taps = (int)t[4];
+  d.co_stride = t[5]; d.ci_stride = t[6];
+  d.tap_base = (int)t[7]; d.tap_step = (int)t[8]; d.RP = (int)t[9]; d.CP = (int)t[10];
+  d.transpose = (int)t[11]; d.row0 = (int)t[12]; d.col0 = (int)t[13];
+  d.rows = (int)(t[14] & 0xffffffff); d.cols = (int)(t[14] >> 32); d.wino = (int)t[15];
+  const long total = (long)d.taps * d.rows * d.cols;
+  const long e0 = (long)local * kPackBlockElems + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < kPackBlockElems / 256; ++k) {
+    const long e = e0 + k * 256;
+    if (e < total) pack_element(d, e);
   }
 }
 
@@ -1607,28 +1646,81 @@ extern "C" int coclr_conv_packed_size(int cin, int cout, int taps, int transpose
   return 0;
 }
 
-extern "C" int coclr_conv_pack_weights(const float* w, float* packed, int cout, int cin, int taps,
-                                       int64_t co_stride, int64_t ci_stride, int tap_base,
-                                       int tap_step, int transpose, int row0, int rows_total,
-                                       int col0, int cols_total, void* stream) {
+namespace {
+
+// Validate one pack request and express it as a PackDesc.
+int pack_describe(const float* w, float* packed, int cout, int cin, int taps, int64_t co_stride,
+                  int64_t ci_stride, int tap_base, int tap_step, int transpose, int row0,
+                  int rows_total, int col0, int cols_total, PackDesc* d) {
   // bit 1: Winograd operand -- taps = 4: F(2,3) of a 3-tap temporal stencil, taps = 16:
   // F(2x2,3x3) of a 9-tap spatial stencil
   const int wino = (transpose >> 1) & 1;
   transpose &= 1;
+  if (cout <= 0 || cin <= 0 || taps <= 0) return COCLR_EINVAL;
   if (wino && taps != 4 && taps != 16) return COCLR_EINVAL;
   if (wino && taps == 16 && rows_total > 0 && cols_total > 0) return COCLR_EINVAL;   // stand-alone only
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
   const bool placed = rows_total > 0 && cols_total > 0;
   if (placed && (row0 < 0 || col0 < 0 || row0 + r > rows_total || col0 + c > cols_total))
     return COCLR_EINVAL;
-  const int RP = pad_to(placed ? rows_total : r, 32), CP = pad_to(placed ? cols_total : c, 128);
-  const int rows = placed ? r : RP, cols = placed ? c : CP;
-  const long total = (long)taps * rows * cols;
+  d->w = w; d->dst = packed;
+  d->Cout = cout; d->Cin = cin; d->taps = taps;
+  d->co_stride = (long)co_stride; d->ci_stride = (long)ci_stride;
+  d->tap_base = tap_base; d->tap_step = tap_step;
+  d->RP = pad_to(placed ? rows_total : r, 32);
+  d->CP = pad_to(placed ? cols_total : c, 128);
+  d->transpose = transpose;
+  d->row0 = placed ? row0 : 0; d->col0 = placed ? col0 : 0;
+  d->rows = placed ? r : d->RP; d->cols = placed ? c : d->CP;
+  d->wino = wino;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int coclr_conv_pack_weights(const float* w, float* packed, int cout, int cin, int taps,
+                                       int64_t co_stride, int64_t ci_stride, int tap_base,
+                                       int tap_step, int transpose, int row0, int rows_total,
+                                       int col0, int cols_total, void* stream) {
+  PackDesc d;
+  int rc = pack_describe(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, tap_step,
+                         transpose, row0, rows_total, col0, cols_total, &d);
+  if (rc) return rc;
+  const long total = (long)d.taps * d.rows * d.cols;
   int blocks = cdiv(total, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                     packed, cout, cin, taps, (long)co_stride, (long)ci_stride, tap_base, tap_step,
-                     RP, CP, transpose, placed ? row0 : 0, placed ? col0 : 0, rows, cols, wino);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_conv_pack_describe(const float* w, float* packed, int cout, int cin, int taps,
+                                        int64_t co_stride, int64_t ci_stride, int tap_base,
+                                        int tap_step, int transpose, int row0, int rows_total,
+                                        int col0, int cols_total, int64_t* entry,
+                                        int32_t* nblocks) {
+  PackDesc d;
+  int rc = pack_describe(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, tap_step,
+                         transpose, row0, rows_total, col0, cols_total, &d);
+  if (rc) return rc;
+  if (!entry || !nblocks) return COCLR_EINVAL;
+  entry[0] = (int64_t)(uintptr_t)d.w; entry[1] = (int64_t)(uintptr_t)d.dst;
+  entry[2] = d.Cout; entry[3] = d.Cin; entry[4] = d.taps;
+  entry[5] = d.co_stride; entry[6] = d.ci_stride;
+  entry[7] = d.tap_base; entry[8] = d.tap_step; entry[9] = d.RP; entry[10] = d.CP;
+  entry[11] = d.transpose; entry[12] = d.row0; entry[13] = d.col0;
+  entry[14] = (int64_t)(uint32_t)d.rows | ((int64_t)d.cols << 32);
+  entry[15] = d.wino;
+  *nblocks = (int32_t)cdiv((long)d.taps * d.rows * d.cols, (long)kPackBlockElems);
+  return 0;
+}
+
+extern "C" int coclr_conv_pack_batch(const int64_t* table, const int32_t* blockmap, int nblocks,
+                                     void* stream) {
+  if (nblocks < 0 || (nblocks > 0 && (!table || !blockmap))) return COCLR_EINVAL;
+  if (nblocks == 0) return 0;
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0,
+                     (hipStream_t)stream, table, blockmap);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

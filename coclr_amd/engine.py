@@ -25,6 +25,9 @@ from . import ops
 
 
 _PACK_STORE = {}      # id(weight) -> (weakref, {use -> packed buffer})
+# One launch re-lays every weight operand of a module's pass (recorded on its first pass) instead
+# of ~80 five-microsecond launches threaded between the convolutions.
+BATCH_PACK = os.environ.get("COCLR_BATCH_PACK", "1") != "0"
 WGRAD_STREAM = os.environ.get("COCLR_WGRAD_STREAM", "1") != "0"
 # Inception branches on their own streams: correct (GPU tier passes with it on) but SLOWER on
 # MI355X -- 47.3 vs 43.3 ms/step: ~160 fork/join points per step cost more in cross-queue
@@ -57,6 +60,74 @@ class _Lane:
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
         return False
+
+
+class PackPlan:
+    """The weight re-layouts one module pass asks for (forward operands and, when the pass is
+    differentiated, the transposed ones its backward uses), replayed as ONE kernel launch at the
+    start of every later pass.  Weights may only change between passes (optimiser / momentum
+    update), which is exactly when the launch scripts change them."""
+
+    def __init__(self):
+        self.requests = {}      # key -> (args, kwargs) of ops.conv_pack_weights
+        self.table = None
+        self.blockmap = None
+        self.dirty = False
+
+    def note(self, key, args, kw):
+        if key not in self.requests:
+            self.requests[key] = (args, kw)
+            self.dirty = True
+
+    def reset(self):
+        self.requests.clear()
+        self.table = self.blockmap = None
+        self.dirty = False
+
+    def build(self, device):
+        rows, bmap = [], []
+        self._ptrs = []
+        for i, (args, kw) in enumerate(self.requests.values()):
+            row, nb = ops.conv_pack_describe(*args, **kw)
+            rows.append(row)
+            bmap.extend((i, b) for b in range(nb))
+            self._ptrs.append((args[0], args[0].data_ptr(), args[1], args[1].data_ptr()))
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.blockmap = torch.tensor(bmap, dtype=torch.int32).to(device)
+        self.dirty = False
+
+    def launch(self, device):
+        """Re-lay everything recorded so far; False when there is nothing to replay (first pass,
+        or the table cannot be (re)built inside a stream capture)."""
+        if not self.requests:
+            return False
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if self.dirty or self.table is None:
+            if capturing:
+                return False
+            self.build(device)
+        # the table holds raw pointers: parameters re-created since (.to(), load with assign, ...)
+        # invalidate it
+        for w, wp, buf, bp in self._ptrs:
+            if w.data_ptr() != wp or buf.data_ptr() != bp:
+                self.reset()
+                return False
+        ops.conv_pack_batch(self.table, self.blockmap, list(self.requests.values()))
+        return True
+
+
+def _plan_for(module, save, device):
+    if not BATCH_PACK:
+        return None
+    plans = module.__dict__.get("_coclr_packplans")
+    if plans is None:
+        plans = module.__dict__["_coclr_packplans"] = {}
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (bool(save), stream, device)
+    plan = plans.get(key)
+    if plan is None:
+        plan = plans[key] = PackPlan()
+    return plan
 
 
 class Val:
@@ -100,6 +171,14 @@ class Run:
         self.param_grads = {}  # id(param) -> grad tensor
         self.no_grad_bases = set()
         self.out = None
+        self.plan = None       # PackPlan of the module being run
+        self.batched = False   # the plan's launch has re-laid its operands for this pass
+
+    def begin(self, module):
+        """Attach the module's pack plan and replay it."""
+        self.plan = _plan_for(module, self.save, self.device)
+        if self.plan is not None:
+            self.batched = self.plan.launch(self.device)
 
     # -- allocation helpers ------------------------------------------------------
     def empty(self, *shape, dtype=torch.float32):
@@ -237,8 +316,8 @@ class Run:
             vt = 4 if kt == 3 else 16
             n = ops.conv_packed_size(cin, cout, vt, transpose)
             packed = self._packed_buffer(w, ("wino", bool(transpose)), n, False)
-            ops.conv_pack_weights(w, packed, cout, cin, vt, cin * kt * kh * kw, kt * kh * kw, 0,
-                                  int(bool(transpose)) | 2, 1)
+            self._relayout(w, packed, (cout, cin, vt, cin * kt * kh * kw, kt * kh * kw, 0,
+                                       int(bool(transpose)) | 2, 1), {})
             return packed
         if taps is not None:
             base = tap_base
@@ -248,8 +327,8 @@ class Run:
             taps, base = kh * kw, kt_slice * kh * kw
         n = ops.conv_packed_size(cin, cout, taps, transpose)
         packed = self._packed_buffer(w, (bool(transpose), taps, base, tap_step), n, False)
-        ops.conv_pack_weights(w, packed, cout, cin, taps, cin * kt * kh * kw, kt * kh * kw, base,
-                              transpose, tap_step)
+        self._relayout(w, packed, (cout, cin, taps, cin * kt * kh * kw, kt * kh * kw, base,
+                                   int(bool(transpose)), tap_step), {})
         return packed
 
     def pack_concat(self, weights, transpose):
@@ -265,13 +344,24 @@ class Run:
         for w in weights:
             cout = w.shape[0]
             if transpose:
-                ops.conv_pack_weights(w, packed, cout, cin, 1, cin, 1, 0, True, 1,
-                                      row0=c0, rows_total=ctot, col0=0, cols_total=cin)
+                self._relayout(w, packed, (cout, cin, 1, cin, 1, 0, 1, 1),
+                               dict(row0=c0, rows_total=ctot, col0=0, cols_total=cin))
             else:
-                ops.conv_pack_weights(w, packed, cout, cin, 1, cin, 1, 0, False, 1,
-                                      row0=0, rows_total=cin, col0=c0, cols_total=ctot)
+                self._relayout(w, packed, (cout, cin, 1, cin, 1, 0, 0, 1),
+                               dict(row0=0, rows_total=cin, col0=c0, cols_total=ctot))
             c0 += cout
         return packed
+
+    def _relayout(self, w, packed, args, kw):
+        """ops.conv_pack_weights(w, packed, *args, **kw), unless this pass's batch launch has
+        already done it; recorded for the batch launch of later passes."""
+        plan = self.plan
+        if plan is not None:
+            key = (id(w), packed.data_ptr(), args, tuple(sorted(kw.items())))
+            if self.batched and key in plan.requests:
+                return
+            plan.note(key, (w, packed) + args, kw)
+        ops.conv_pack_weights(w, packed, *args, **kw)
 
 
 # ---------------------------------------------------------------------------------
@@ -594,6 +684,7 @@ class EngineFn(torch.autograd.Function):
         xin = Val(x if _dense5(x) else x.contiguous())
         if not need_dx:
             run.no_grad_bases.add(id(xin.base))
+        run.begin(module)
         run.out = module._emit(run, xin, **kwargs)
         ctx.run = run
         ctx.xin = xin
@@ -629,5 +720,10 @@ def run_module(module, x, **kwargs):
         return EngineFn.apply(module, kwargs, x, *params)
     run = Run(x.device, save=False)
     xin = Val(x if _dense5(x) else x.contiguous())
+    run.begin(module)
     out = module._emit(run, xin, **kwargs).view()
+    plan = run.plan
+    if plan is not None and plan.dirty and not (
+            x.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        plan.build(x.device)      # ready before a caller captures the next pass into a hipGraph
     return out if out.is_contiguous() else out.contiguous()

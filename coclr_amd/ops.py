@@ -256,6 +256,25 @@ def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base
         int(transpose), row0, rows_total, col0, cols_total, _stream()), "conv_pack_weights")
 
 
+def conv_pack_describe(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose,
+                       tap_step=1, row0=0, rows_total=0, col0=0, cols_total=0):
+    """One row of a batch-pack table (16 int64) and the number of 1024-element blocks it takes;
+    same arguments as conv_pack_weights."""
+    entry = (C.c_int64 * 16)()
+    nb = C.c_int32()
+    _lib.check(_L().coclr_conv_pack_describe(
+        _p(w), _p(packed), cout, cin, taps, co_stride, ci_stride, tap_base, tap_step,
+        int(transpose), row0, rows_total, col0, cols_total, entry, C.byref(nb)), "conv_pack_describe")
+    return list(entry), nb.value
+
+
+def conv_pack_batch(table, blockmap, requests=None):
+    """Launch every re-layout of a table built from conv_pack_describe rows.  `requests` (the
+    argument tuples the rows were made from) is unused here; the CPU test double replays them."""
+    _lib.check(_L().coclr_conv_pack_batch(_p(table, torch.int64), _p(blockmap, torch.int32),
+                                          blockmap.shape[0], _stream()), "conv_pack_batch")
+
+
 def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shift=None,
              n_index=None, relu=False, accumulate=False):
     d = geom.desc

@@ -81,6 +81,19 @@ int coclr_conv_pack_weights(const float* w, float* packed, int cout, int cin, in
                             int transpose, int row0, int rows_total, int col0, int cols_total,
                             void* stream);
 
+/* The same re-layouts, many at once (every operand of an encoder: ~80 tiny launches per pass
+ * otherwise).  coclr_conv_pack_describe validates one request exactly as
+ * coclr_conv_pack_weights would and writes it as a 16-word table row plus the number of
+ * 1024-element blocks it needs; the caller uploads the rows and a block map
+ * int32[nblocks][2] = {row, block index within the row} and launches them all with
+ * coclr_conv_pack_batch.  The pointers in a row must stay valid for every replay. */
+int coclr_conv_pack_describe(const float* w, float* packed, int cout, int cin, int taps,
+                             int64_t co_stride, int64_t ci_stride, int tap_base, int tap_step,
+                             int transpose, int row0, int rows_total, int col0, int cols_total,
+                             int64_t* entry, int32_t* nblocks);
+int coclr_conv_pack_batch(const int64_t* table, const int32_t* blockmap, int nblocks,
+                          void* stream);
+
 /* Number of per-workgroup BatchNorm partial sums coclr_conv3d_fwd will emit
  * per channel for this geometry (stats buffer = 2 * Cout * ntiles floats). */
 int coclr_conv3d_ntiles(const coclr_conv_desc* d, int* ntiles);

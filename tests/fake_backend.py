@@ -51,6 +51,16 @@ def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base
     dst[:, row0:row0 + r, col0:col0 + c] = src
 
 
+def conv_pack_describe(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base, transpose,
+                       tap_step=1, row0=0, rows_total=0, col0=0, cols_total=0):
+    return [0] * 16, 1
+
+
+def conv_pack_batch(table, blockmap, requests=None):
+    for args, kw in requests:
+        conv_pack_weights(*args, **kw)
+
+
 def _unpack(geom, wp):
     taps = geom.taps
     if getattr(geom, "algo", 0) == 1:

@@ -542,3 +542,57 @@ def test_conv_spatial_winograd(case):
     close(wide[:, 8:], ref, what="winograd into a channel slice")
     assert float(wide[:, :8].abs().max()) == 0.0
 
+
+
+def test_pack_batch_matches_single_launches():
+    """coclr_conv_pack_describe + coclr_conv_pack_batch re-lay a mixed set of operands (forward,
+    data-gradient, tap subsets, both Winograd forms, sub-blocks placed in a concatenated operand)
+    bit-identically to one coclr_conv_pack_weights launch each."""
+    from coclr_amd import ops
+    torch.manual_seed(11)
+    reqs = []     # (w, size, args, kw)
+
+    def add(w, taps_packed, transpose, args):
+        cout, cin = w.shape[:2]
+        reqs.append((w, ops.conv_packed_size(cin, cout, taps_packed, transpose), args, {}))
+
+    w133 = dev(torch.randn(208, 48, 1, 3, 3))
+    w311 = dev(torch.randn(96, 64, 3, 1, 1))
+    w711 = dev(torch.randn(64, 64, 7, 1, 1))
+    w111a, w111b = dev(torch.randn(40, 72, 1, 1, 1)), dev(torch.randn(24, 72, 1, 1, 1))
+    add(w133, 9, 0, (208, 48, 9, 48 * 9, 9, 0, 0, 1))
+    add(w133, 9, 1, (208, 48, 9, 48 * 9, 9, 0, 1, 1))
+    add(w133, 16, 0, (208, 48, 16, 48 * 9, 9, 0, 2, 1))
+    add(w133, 16, 1, (208, 48, 16, 48 * 9, 9, 0, 3, 1))
+    add(w311, 4, 0, (96, 64, 4, 64 * 3, 3, 0, 2, 1))
+    add(w311, 4, 1, (96, 64, 4, 64 * 3, 3, 0, 3, 1))
+    add(w711, 4, 1, (64, 64, 4, 64 * 7, 7, 0, 1, 2))          # taps 0,2,4,6: one dgrad phase
+    add(w711, 3, 1, (64, 64, 3, 64 * 7, 7, 1, 1, 2))          # taps 1,3,5
+    ncat = ops.conv_packed_size(72, 64, 1, 0)
+    reqs.append((w111a, ncat, (40, 72, 1, 72, 1, 0, 0, 1), dict(row0=0, rows_total=72, col0=0, cols_total=64)))
+    reqs.append((w111b, ncat, (24, 72, 1, 72, 1, 0, 0, 1), dict(row0=0, rows_total=72, col0=40, cols_total=64)))
+    single = [torch.zeros(n, device="cuda") for _, n, _, _ in reqs]
+    batch = [torch.zeros(n, device="cuda") for _, n, _, _ in reqs]
+    batch[-1] = batch[-2]; single[-1] = single[-2]            # the two heads share one operand
+    rows, bmap = [], []
+    for i, (w, n, args, kw) in enumerate(reqs):
+        ops.conv_pack_weights(w, single[i], *args, **kw)
+        row, nb = ops.conv_pack_describe(w, batch[i], *args, **kw)
+        assert nb == -(-_pack_elems(args, kw) // 1024)
+        rows.append(row)
+        bmap.extend((i, b) for b in range(nb))
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    blockmap = torch.tensor(bmap, dtype=torch.int32).cuda()
+    ops.conv_pack_batch(table, blockmap)
+    for i in range(len(reqs)):
+        assert torch.equal(single[i], batch[i]), "operand %d differs" % i
+    assert float(single[2].abs().sum()) > 0
+
+
+def _pack_elems(args, kw):
+    cout, cin, taps = args[0], args[1], args[2]
+    transpose = args[6] & 1
+    r, c = (cout, cin) if transpose else (cin, cout)
+    if kw:
+        return taps * r * c
+    return taps * ((r + 31) // 32 * 32) * ((c + 127) // 128 * 128)
