@@ -462,9 +462,13 @@ class InfoNCE(nn.Module):
             ops.gather_rows(src, n_index, static_x)
             torch.cuda.current_stream(dev).synchronize()
             g = torch.cuda.CUDAGraph()
+            # Capture on the stream the eager call ran on (the key stream) when there is one: the
+            # packed-operand buffers and the batch re-layout plan recorded by that call are per
+            # stream, so the graph then holds ONE re-layout launch instead of 77.
+            cur = torch.cuda.current_stream(dev)
+            cap = cur if cur != torch.cuda.default_stream(dev) else torch.cuda.Stream(device=dev)
             # thread-local capture: RCCL's watchdog thread keeps polling events meanwhile
-            with torch.cuda.graph(g, stream=torch.cuda.Stream(device=dev),
-                                  capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
                 if pre is not None:
                     pre()
                 out = self._encode(encoder, static_x)
