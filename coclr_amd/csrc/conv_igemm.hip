@@ -34,7 +34,6 @@
 //     accumulate, plus per-workgroup partial sums (sum, sum of squares) per
 //     output channel for train-mode BatchNorm, reduced with DPP row operations
 //     and written without atomics as [2][Cout][ntiles].
-#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
