@@ -215,3 +215,59 @@ def test_routed_shuffle_plan_delivers_every_clip_once(world, B):
                 recv += chunk
             assert len(recv) == B
             assert [recv[p] for p in pos] == perm[r * B:(r + 1) * B]
+
+
+def test_pack_plan_replays_recorded_relayouts(fake, monkeypatch):
+    """engine.PackPlan: the first pass of a module launches its weight re-layouts one by one and
+    records them; later passes replay them as one batch and skip the single launches (forward and
+    backward operands alike); results do not change; moving a parameter re-records."""
+    from coclr_amd import engine, ops
+    from backbone.select_backbone import select_backbone
+    torch.manual_seed(3)
+    net, _ = select_backbone("s3d")
+    mod = net.Mixed_3b
+    x = torch.randn(2, 192, 4, 8, 8, requires_grad=True)
+    calls = {"single": 0, "batch": 0}
+    single, batch = ops.conv_pack_weights, ops.conv_pack_batch
+
+    def count_single(*a, **k):
+        calls["single"] += 1
+        return single(*a, **k)
+
+    def count_batch(*a, **k):
+        calls["batch"] += 1
+        return batch(*a, **k)
+
+    monkeypatch.setattr(ops, "conv_pack_weights", count_single)
+    monkeypatch.setattr(ops, "conv_pack_batch", count_batch)
+
+    def step():
+        for p in mod.parameters():
+            p.grad = None
+        x.grad = None
+        y = engine.run_module(mod, x)
+        y.square().mean().backward()
+        return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in mod.parameters()]
+
+    y1, dx1, g1 = step()
+    n_first = calls["single"]
+    assert n_first > 0 and calls["batch"] == 0
+    calls["single"] = 0
+    y2, dx2, g2 = step()
+    # the fake's batch replays the recorded requests through its own single-request routine,
+    # which is not the patched name: no single launches are issued by the engine itself
+    assert calls["batch"] == 1 and calls["single"] == 0
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+    plan, = [p for p in mod.__dict__["_coclr_packplans"].values()]
+    assert len(plan.requests) == n_first
+    # a parameter that moved (e.g. module.to(...)) invalidates the table: that pass re-records
+    w = next(mod.parameters())
+    w.data = w.data.clone()
+    calls.update(single=0, batch=0)
+    y3, dx3, _ = step()
+    assert calls["batch"] == 0 and calls["single"] == n_first
+    assert torch.equal(y1, y3) and torch.equal(dx1, dx3)
+    calls.update(single=0, batch=0)
+    step()
+    assert calls["batch"] == 1 and calls["single"] == 0
