@@ -311,7 +311,7 @@ class Run:
         one temporal slice of the stencil; (taps, tap_base, tap_step) an arithmetic subset;
         algo=1 the Winograd-domain matrices of a (3,1,1) or (1,3,3) stencil."""
         cout, cin, kt, kh, kw = w.shape
-        if algo == 1:
+        if algo >= 1:
             # (3,1,1): 4 matrices of F(2,3); (1,3,3): 16 matrices of F(2x2,3x3)
             vt = 4 if kt == 3 else 16
             n = ops.conv_packed_size(cin, cout, vt, transpose)

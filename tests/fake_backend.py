@@ -63,7 +63,7 @@ def conv_pack_batch(table, blockmap, requests=None):
 
 def _unpack(geom, wp):
     taps = geom.taps
-    if getattr(geom, "algo", 0) == 1:
+    if getattr(geom, "algo", 0) >= 1:
         slots = 4 if taps == 3 else 16
         w = wp.view(slots, _r32(geom.Cin), _r128(geom.Cout))[:taps, :geom.Cin, :geom.Cout]
         return w.permute(2, 1, 0).reshape(geom.Cout, geom.Cin, *geom.k).contiguous()
