@@ -291,7 +291,9 @@ def main():
                      "algorithmic_gbs_per_gpu": round(2145e6 * B / (ms * 1e-3) / 1e9, 1),
                      "frac_hbm_peak": round(2145e6 * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         rec = {
-            "metric": "clips/sec (whole node) S3D-InfoNCE seq_len=32 bs=32/GPU",
+            "metric": "clips/sec (whole node) %s-%s seq_len=%d bs=%d/GPU" % (
+                {"s3d": "S3D", "s3dg": "S3D-G", "r50": "R2D3D50"}.get(args.net, args.net),
+                {"infonce": "InfoNCE", "coclr": "CoCLR"}[args.model], args.seq_len, B),
             "value": round(clips, 2), "unit": "clips/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",

@@ -271,3 +271,29 @@ def test_pack_plan_replays_recorded_relayouts(fake, monkeypatch):
     calls.update(single=0, batch=0)
     step()
     assert calls["batch"] == 1 and calls["single"] == 0
+
+
+def test_winograd_policy():
+    """ops.conv_geom(): which convolutions go through the Winograd kernels (capability vs policy)."""
+    from coclr_amd import ops
+    if not (ops.WINOGRAD and ops.WINOGRAD_HW):
+        pytest.skip("Winograd switched off by the environment")
+    # temporal halves of the separable units: always, from 16 input channels up
+    assert ops.conv_geom(4, 64, 64, (8, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0)).algo == 1
+    assert ops.conv_geom(4, 8, 64, (8, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0)).algo == 0
+    assert ops.conv_geom(4, 64, 64, (8, 8, 8), (3, 1, 1), (2, 1, 1), (1, 0, 0)).algo == 0
+    # spatial halves: 16x16 maps and up, even extents, stride 1
+    hw = ops.WINOGRAD_HW_ALGO
+    assert ops.conv_geom(4, 64, 192, (4, 32, 32), (1, 3, 3), (1, 1, 1), (0, 1, 1)).algo == hw
+    assert ops.conv_geom(4, 96, 128, (4, 16, 16), (1, 3, 3), (1, 1, 1), (0, 1, 1)).algo == hw
+    assert ops.conv_geom(4, 96, 208, (4, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1)).algo == 0
+    assert ops.conv_geom(4, 96, 208, (4, 17, 17), (1, 3, 3), (1, 1, 1), (0, 1, 1)).algo == 0
+    assert ops.conv_geom(4, 64, 64, (4, 32, 32), (1, 3, 3), (1, 2, 2), (0, 1, 1)).algo == 0
+    # the kernels themselves accept the small even maps (capability), and the data gradient of a
+    # Winograd conv is a Winograd conv
+    g = ops.ConvGeom(2, 32, 48, (3, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1), algo=1)
+    assert g.dgrad().algo == 1 and g.dgrad().Cin == 48 and g.dgrad().Cout == 32
+    with pytest.raises(ValueError):
+        ops.ConvGeom(2, 32, 48, (3, 7, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1), algo=1)
+    with pytest.raises(ValueError):
+        ops.ConvGeom(2, 32, 48, (3, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0), algo=2)
