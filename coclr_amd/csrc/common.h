@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define COCLR_WAVE 64
 
@@ -19,6 +20,20 @@
 
 // invalid-argument code shared by all entry points (== hipErrorInvalidValue)
 #define COCLR_EINVAL 1
+
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute belongs to the device's copy of
+// the code object); `done` is a per-call-site bit mask of the devices already configured.  Safe to
+// race: setting the attribute twice is idempotent.
+static inline hipError_t ensure_dyn_lds(const void* kern, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

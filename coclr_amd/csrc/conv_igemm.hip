@@ -699,12 +699,8 @@ int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
   auto kern = conv_wino_t_kernel<CC, BM, BNP, PCH, XV4>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)a.mtiles * a.ntiles)), dim3(256), lds, stream, a);
   COCLR_LAUNCH_CHECK();
   return 0;
@@ -1124,370 +1120,11 @@ int launch_wino_hw(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   const size_t lds = 2 * stage + (size_t)2 * 64 * 64 * sizeof(float) + (size_t)PCH * 256 * sizeof(unsigned);
   if (lds > 160 * 1024) return COCLR_EINVAL;
   auto kern = conv_wino_hw_kernel<CC, PCH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   const long total = (long)a.mtiles * a.ntiles;
   const int grid = total < kWinoGrid ? (int)total : kWinoGrid;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, (int)total);
-  COCLR_LAUNCH_CHECK();
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------
-// F(2x2,3x3) again, TWO waves per SIMD (coclr_conv_desc.algo = 2; opt-in).
-//
-// The kernel above is issue-bound: with one wave per SIMD nothing overlaps that wave's LDS reads,
-// patch transform and address arithmetic with its own MFMAs (46 % MFMA-busy).  Here the 64x64
-// tile is cut eight ways -- 512 threads, wave (wm, wn) owns 32 couts x 16 block positions as two
-// 16x16 MFMA tiles (v_mfma_f32_16x16x4_f32: four channels per step, 4 accumulator registers per
-// transform-domain matrix) -- so a wave needs 2 x 16 x 4 = 128 AGPRs and two waves share a SIMD:
-// one's transform runs under the other's MFMAs.  Per step of four channels a wave reads its 2x16
-// weights as eight ds_read_b128, ONE 4x4 patch (shared by both cout tiles) as four ds_read2_b64,
-// transforms it (28 VALU) and issues 32 MFMAs.  Same persistent tile walk, LDS stream, packed
-// operand, window table and statistics partials as above; outputs are stored straight from the
-// epilogue (64 pending registers do not fit a 128-VGPR wave; the second wave on the SIMD hides
-// the store issue instead).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int CC, int PCH>
-__global__ void __launch_bounds__(512)
-conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
-  constexpr int BM = 64;
-  constexpr int WPIECES = 16 * CC / 4;          // 1 KiB weight pieces per chunk
-  static_assert(CC == 8, "one window channel per wave, two 4-channel steps per chunk");
-  constexpr int W_FLOATS = 16 * CC * BM;
-  constexpr int QS = CC / 4;
-
-  extern __shared__ __align__(16) float smem[];
-  const int planeS = a.planeS;
-  const int stage_floats = W_FLOATS + CC * planeS;
-  float* redS = smem + 2 * stage_floats;        // [BM][64] partial sums, one per block position
-  float* redQ = redS + BM * 64;
-  unsigned* wtab = reinterpret_cast<unsigned*>(redQ + BM * 64);     // [PCH][64]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ln = lane & 15, lk = lane >> 4;     // MFMA operand row/column and channel of the step
-  const int wm = wave >> 2, wn = wave & 3;
-  const int plane = a.plane;
-  const int WW = a.WW;
-
-  const int nwg = (int)gridDim.x;
-  int tile = (nwg % 8 == 0) ? ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
-  if (tile >= total_tiles) return;
-
-  const unsigned wvoff = (unsigned)lane * 16u;
-  {
-    // every wave writes the same table (its own lanes read it back: no barrier needed)
-    const int hw = a.WH * WW;
-#pragma unroll
-    for (int j = 0; j < PCH; ++j) {
-      const int e = j * 64 + lane;
-      unsigned crd = 0xffffffffu;
-      if (e < plane) {
-        const int wn_ = fdiv(e, a.inv_plane1);
-        int q = e - wn_ * a.plane1;
-        const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
-        const int wh = fdiv(q, a.inv_ww);
-        const int ww = q - wh * WW;
-        crd = (unsigned)ww | ((unsigned)wh << 8) | ((unsigned)wt << 16) | ((unsigned)wn_ << 24);
-      }
-      wtab[j * 64 + lane] = crd;
-    }
-  }
-
-  // block position of this lane (column of the B operand / of the output tile)
-  int lanebase, ptw, pth, ptt, ptn;
-  {
-    const int p = wn * 16 + ln;
-    ptw = p & ((1 << a.lTW) - 1);
-    pth = (p >> a.lTW) & ((1 << a.lTH) - 1);
-    ptt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
-    ptn = p >> (a.lTW + a.lTH + a.lTT);
-    lanebase = W_FLOATS + ptn * a.plane1 + (ptt * a.WH + pth * 2) * WW + ptw * 2 + lk * planeS;
-  }
-  // weights in LDS: [c][m][16 xi], quads rotated by m>>2; cout tile s of this wave: rows +16s
-  const int abase = (lk * BM + wm * 32 + ln) * 16;
-  const int arot = (ln >> 2) & 3;
-  const __amdgpu_buffer_rsrc_t rw =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
-
-  int ntile, n0, ot0, oh0, ow0, cout0;
-  unsigned goff[PCH];
-  __amdgpu_buffer_rsrc_t rx;
-  auto setup = [&](int t) {
-    const int mt = t % a.mtiles;
-    ntile = t / a.mtiles;
-    int r = ntile;
-    const int bw_ = r % a.nbw; r /= a.nbw;
-    const int bh_ = r % a.nbh; r /= a.nbh;
-    const int bt_ = r % a.nbt; r /= a.nbt;
-    n0 = r << a.lTN;
-    ow0 = bw_ << a.lTW; oh0 = bh_ << a.lTH; ot0 = bt_ << a.lTT;
-    cout0 = mt * BM;
-    const int vt0 = ot0, vh0 = oh0 * 2 - 1, vw0 = ow0 * 2 - 1;
-#pragma unroll
-    for (int j = 0; j < PCH; ++j) {
-      const unsigned c = wtab[j * 64 + lane];
-      const int ww = (int)(c & 255u), wh = (int)((c >> 8) & 255u), wt = (int)((c >> 16) & 255u),
-                wn_ = (int)(c >> 24);
-      const int iw = vw0 + ww, ih = vh0 + wh, it = vt0 + wt, n = n0 + wn_;
-      const bool ok = c != 0xffffffffu && n < a.N && it < a.Ti && (unsigned)ih < (unsigned)a.Hi &&
-                      (unsigned)iw < (unsigned)a.Wi;
-      const long off = (long)wn_ * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw;
-      goff[j] = ok ? (unsigned)off * 4u : OOB;
-    }
-    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)n0 * a.x_nstride), 0, BUF_RANGE,
-                                           0x00020000);
-  };
-
-  // chunk DMA: wave w brings weight pieces w, w+8, w+16, w+24 (piece p = quarter p&3 of channel
-  // row p>>2) and window channel w
-  auto stage = [&](int cin0, float* sbase) {
-    {
-      unsigned soff = (unsigned)((((long)(cin0 + (wave >> 2)) * a.CoutP + cout0) * 16 + (wave & 3) * 256) * 4);
-      const unsigned sstep = (unsigned)a.CoutP * 128u;      // two channel rows on
-      float* dst = sbase + wave * 256;
-#pragma unroll
-      for (int k = 0; k < WPIECES / 8; ++k) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(dst), 16, wvoff, soff, 0, 0);
-        soff += sstep;
-        dst += 2048;
-      }
-    }
-    float* xs = sbase + W_FLOATS + wave * planeS;
-    const int cin = cin0 + wave;
-    if (cin < a.Cin) {
-      const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
-#pragma unroll
-      for (int j = 0; j < PCH; ++j)
-        if (j * 64 < plane)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + j * 64), 4, goff[j], soff, 0, 0);
-    } else {
-#pragma unroll
-      for (int j = 0; j < PCH; ++j)
-        if (j * 64 < plane) xs[j * 64 + lane] = 0.f;
-    }
-  };
-
-  const int nchunks = a.nchunks;
-  const bool want_stats = a.stats != nullptr;
-  const unsigned lane_rows = (unsigned)lk * 4u * (unsigned)a.y_cstride * 4u;
-  const unsigned row_bytes = (unsigned)a.yWf * 4u;
-
-  setup(tile);
-  stage(0, smem);
-  int G = 0;
-
-  for (;;) {
-    f32x4 acc[2][16];
-#pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[s_][t][i] = 0.f;
-
-    for (int ch = 0; ch < nchunks; ++ch, ++G) {
-      const float* cur = smem + (G & 1) * stage_floats;
-      __builtin_amdgcn_s_waitcnt(0x0f70);
-      __syncthreads();
-      if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((G + 1) & 1) * stage_floats);
-
-      // step q: channels 4q .. 4q+3 (this lane: 4q + lk)
-      auto fetch_a_quad = [&](int q, int s_, int g, float (&av)[16]) {
-        const float4 v = *reinterpret_cast<const float4*>(
-            &cur[abase + s_ * 16 * 16 + 4 * q * BM * 16 + ((g + arot) & 3) * 4]);
-        av[4 * g + 0] = v.x; av[4 * g + 1] = v.y; av[4 * g + 2] = v.z; av[4 * g + 3] = v.w;
-      };
-      auto fetch_d = [&](int q, f32x2 (&dv)[8]) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float* src = &cur[lanebase + rr * WW + 4 * q * planeS];
-          dv[2 * rr] = *reinterpret_cast<const f32x2*>(src);
-          dv[2 * rr + 1] = *reinterpret_cast<const f32x2*>(src + 2);
-        }
-      };
-      auto transform = [&](const f32x2 (&dv)[8], float (&V)[16]) {
-        f32x2 tl[4], th[4];
-        tl[0] = dv[0] - dv[4]; th[0] = dv[1] - dv[5];
-        tl[1] = dv[2] + dv[4]; th[1] = dv[3] + dv[5];
-        tl[2] = dv[4] - dv[2]; th[2] = dv[5] - dv[3];
-        tl[3] = dv[2] - dv[6]; th[3] = dv[3] - dv[7];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          V[4 * i + 0] = tl[i].x - th[i].x;
-          V[4 * i + 1] = tl[i].y + th[i].x;
-          V[4 * i + 2] = th[i].x - tl[i].y;
-          V[4 * i + 3] = tl[i].y - th[i].y;
-        }
-      };
-      // The chunk is four blocks of 16 MFMAs: (step q, cout tile s) = (0,0) (0,1) (1,0) (1,1).
-      // Every buffer is single: a weight quad of av is refilled for the next block as soon as its
-      // four MFMAs have gone, the patch of step 1 is fetched once step 0's has been transformed
-      // and transformed when step 0's MFMAs are out.  The wave's own latencies are covered by
-      // the other wave of the SIMD.
-      float av[16], V[16];
-      f32x2 dv[8];
-      fetch_d(0, dv);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) fetch_a_quad(0, 0, g, av);
-      transform(dv, V);
-      if (QS > 1) fetch_d(1, dv);
-#pragma unroll
-      for (int b = 0; b < 2 * QS; ++b) {
-        const int q = b >> 1, s_ = b & 1;
-        __builtin_amdgcn_sched_barrier(0);
-        if (s_ == 0 && q > 0) {
-          transform(dv, V);
-          if (q + 1 < QS) fetch_d(q + 1, dv);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            acc[s_][4 * g + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                av[4 * g + k], V[4 * g + k], acc[s_][4 * g + k], 0, 0, 0);
-          if (b + 1 < 2 * QS) fetch_a_quad((b + 1) >> 1, (b + 1) & 1, g, av);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- epilogue --------------------------------------------------------------------------
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.y + (long)n0 * a.y_nstride), 0, BUF_RANGE, 0x00020000);
-    unsigned yvoff;
-    bool pvalid;
-    {
-      const int n = n0 + ptn, ot = ot0 + ptt, oh = oh0 + pth, ow = ow0 + ptw;
-      pvalid = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
-      const long e = (long)ptn * a.y_nstride + ((long)ot * a.yHf + 2 * oh) * a.yWf + 2 * ow;
-      yvoff = pvalid ? (unsigned)(e * 4) + lane_rows : OOB;
-    }
-    const int e_ntile = ntile, e_cout0 = cout0;
-    const int next = tile + nwg;
-    const bool more = next < total_tiles;
-    if (more) {
-      setup(next);
-      stage(0, smem + (G & 1) * stage_floats);
-    }
-
-    auto emit = [&](auto mode_tag) {
-      constexpr int MODE = decltype(mode_tag)::value;
-#pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          // accumulator register i of cout tile s_: output row 4*lk + i of that tile
-          const int rowu = wm * 32 + s_ * 16 + i;          // wave-uniform part
-          const int ml = rowu + 4 * lk;
-          float r0[4], r1[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float m0 = agpr_read(acc[s_][0 + j][i]), m1 = agpr_read(acc[s_][4 + j][i]),
-                        m2 = agpr_read(acc[s_][8 + j][i]), m3 = agpr_read(acc[s_][12 + j][i]);
-            r0[j] = (m0 + m1) + m2;
-            r1[j] = (m1 - m2) - m3;
-          }
-          float v00 = (r0[0] + r0[1]) + r0[2], v01 = (r0[1] - r0[2]) - r0[3];
-          float v10 = (r1[0] + r1[1]) + r1[2], v11 = (r1[1] - r1[2]) - r1[3];
-          const int co = e_cout0 + ml;
-          const bool cok = co < a.Cout;
-          const unsigned soff = (unsigned)(e_cout0 + rowu) * (unsigned)a.y_cstride * 4u;
-          const unsigned vo0 = cok ? yvoff : OOB;
-          const unsigned vo1 = cok && pvalid ? yvoff + row_bytes : OOB;
-          if (MODE == 2 && a.accumulate) {
-            const u32x2 o0 = __builtin_amdgcn_raw_buffer_load_b64(ry, vo0, soff, 0);
-            const u32x2 o1 = __builtin_amdgcn_raw_buffer_load_b64(ry, vo1, soff, 0);
-            v00 += __uint_as_float(o0.x); v01 += __uint_as_float(o0.y);
-            v10 += __uint_as_float(o1.x); v11 += __uint_as_float(o1.y);
-          }
-          if (MODE != 0 && (MODE == 1 || want_stats)) {
-            float s = 0.f, ss = 0.f;
-            if (pvalid) {
-              s = (v00 + v01) + (v10 + v11);
-              ss = (v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11);
-            }
-            redS[ml * 64 + wn * 16 + ln] = s;
-            redQ[ml * 64 + wn * 16 + ln] = ss;
-          }
-          if (MODE == 2) {
-            float bia = 0.f, sc = 1.f, sf = 0.f;
-            if (a.bias && cok) bia = a.bias[co];
-            if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
-            v00 = (v00 + bia) * sc + sf; v01 = (v01 + bia) * sc + sf;
-            v10 = (v10 + bia) * sc + sf; v11 = (v11 + bia) * sc + sf;
-            if (a.relu) {
-              v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f);
-            }
-          }
-          u32x2 s0, s1;
-          s0.x = __float_as_uint(v00); s0.y = __float_as_uint(v01);
-          s1.x = __float_as_uint(v10); s1.y = __float_as_uint(v11);
-          __builtin_amdgcn_raw_buffer_store_b64(s0, ry, vo0, soff, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(s1, ry, vo1, soff, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    };
-    const bool fancy = a.bias || a.ep_scale || a.relu || a.accumulate;
-    if (fancy) emit(std::integral_constant<int, 2>{});
-    else if (want_stats) emit(std::integral_constant<int, 1>{});
-    else emit(std::integral_constant<int, 0>{});
-
-    if (want_stats) {
-      __syncthreads();
-      if (tid < 256) {      // waves 0-3: row t>>2, quarter t&3 of its 64 partials
-        const int row = tid >> 2, qtr = tid & 3;
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 ps = *reinterpret_cast<const float4*>(&redS[row * 64 + qtr * 16 + 4 * k]);
-          const float4 pq = *reinterpret_cast<const float4*>(&redQ[row * 64 + qtr * 16 + 4 * k]);
-          s += (ps.x + ps.y) + (ps.z + ps.w);
-          ss += (pq.x + pq.y) + (pq.z + pq.w);
-        }
-        s += __builtin_amdgcn_update_dpp(0.f, s, 0xB1, 0xf, 0xf, true);
-        s += __builtin_amdgcn_update_dpp(0.f, s, 0x4E, 0xf, 0xf, true);
-        ss += __builtin_amdgcn_update_dpp(0.f, ss, 0xB1, 0xf, 0xf, true);
-        ss += __builtin_amdgcn_update_dpp(0.f, ss, 0x4E, 0xf, 0xf, true);
-        const int co = e_cout0 + row;
-        if (qtr == 0 && co < a.Cout) {
-          a.stats[(long)co * a.ntiles + e_ntile] = s;
-          a.stats[((long)a.Cout + co) * a.ntiles + e_ntile] = ss;
-        }
-      }
-    }
-    if (!more) break;
-    tile = next;
-  }
-}
-
-template <int CC, int PCH>
-int launch_wino_hw8(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
-  if (p.plane > PCH * 64 || p.WW > 255 || p.WH > 255 || p.WT > 255 || p.lTN > 7) return COCLR_EINVAL;
-  a.mtiles = cdiv(a.Cout, 64);
-  a.planeS = cdiv(p.plane, 64) * 64;
-  a.nchunks = cdiv(a.Cin, CC);
-  const size_t stage = ((size_t)16 * CC * 64 + (size_t)CC * a.planeS) * sizeof(float);
-  const size_t lds = 2 * stage + (size_t)2 * 64 * 64 * sizeof(float) + (size_t)PCH * 64 * sizeof(unsigned);
-  if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_wino_hw8_kernel<CC, PCH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  const long total = (long)a.mtiles * a.ntiles;
-  const int grid = total < kWinoGrid ? (int)total : kWinoGrid;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, a, (int)total);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
@@ -1809,12 +1446,8 @@ int launch_stem(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   const size_t lds = ((size_t)W_FLOATS + 2 * (size_t)CIN * a.planeS) * sizeof(float);
   if (lds > 160 * 1024) return COCLR_EINVAL;
   auto kern = conv_stem_kernel<KH, KW, CIN, PCH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   hipLaunchKernelGGL(kern, dim3((unsigned)a.ntiles, (unsigned)a.mtiles), dim3(256), lds, stream, a,
                      p.nboxes);
   COCLR_LAUNCH_CHECK();
@@ -1939,12 +1572,8 @@ int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
   auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PCH, XV4>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   const long blocks = (long)a.mtiles * a.ntiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
   COCLR_LAUNCH_CHECK();
@@ -2098,7 +1727,7 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
       if (p->plane > 256) return COCLR_EINVAL;
       *variant = 3;
     }
-  } else if (kt == 1 && kh == 3 && kw == 3 && (d->algo == 1 || d->algo == 2)) {
+  } else if (kt == 1 && kh == 3 && kw == 3 && d->algo == 1) {
     // Winograd F(2x2,3x3): plan over 2x2 output blocks as a (1,4,4) stencil with stride (1,2,2)
     if (!(p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 0 && p->ph == 1 && p->pw == 1 &&
           p->dt == 1 && p->dh == 1 && p->dw == 1 && p->Hi == p->Ho && p->Wi == p->Wo &&
@@ -2108,7 +1737,7 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
     p->sh = p->sw = 2;
     conv_pick_box(p, 6, 1, 4, 4);
     if (p->plane > 640) return COCLR_EINVAL;
-    *variant = d->algo == 2 ? 61 : 60;
+    *variant = 60;
   } else if (kt == 1 && kh == 3 && kw == 3) {
     c = choose_tile(*p, 1, 3, 3, true, true, 256, 512);
     conv_pick_box(p, c.lbn, 1, 3, 3);
@@ -2241,8 +1870,7 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
       return xv4 ? launch_wino_t<16, 64, 64, 4, true>(a, p, stream)
                  : launch_wino_t<16, 64, 64, 4, false>(a, p, stream);
     }
-    case 60:
-    case 61: {
+    case 60: {
       // a.Ho/Wo = 2x2 blocks; the destination keeps its full row pitch
       if (n_index || ((uintptr_t)y % 8) != 0 || (a.y_nstride % 2) != 0) return COCLR_EINVAL;
       a.yHf = d->Ho; a.yWf = d->Wo;
@@ -2250,8 +1878,6 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
       if ((((double)(1 << p.lTN)) * (double)a.y_nstride + (double)(a.Cout + 128) * a.y_cstride) * 4.0 >= lim)
         return COCLR_EINVAL;
       if (16.0 * a.CinP * a.CoutP * 4.0 >= lim) return COCLR_EINVAL;
-      // the two-waves-per-SIMD form only has the registers for windows of up to six DMA pieces
-      if (variant == 61 && p.plane <= 384) return launch_wino_hw8<8, 6>(a, p, stream);
       return p.plane <= 384 ? launch_wino_hw<8, 6>(a, p, stream) : launch_wino_hw<8, 10>(a, p, stream);
     }
     case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);

@@ -926,12 +926,8 @@ template <int BJ, int PCH>
 int launch_wgrad(WgradArgs& a, const WPlan& w, hipStream_t stream) {
   const size_t lds = ((size_t)64 * 129 + 128 + (size_t)w.nci_max * a.planeP) * sizeof(float);
   auto kern = conv_wgrad_kernel<BJ, PCH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   hipLaunchKernelGGL(kern, dim3(a.S, a.jtiles, a.mtiles), dim3(256), lds, stream, a);
   COCLR_LAUNCH_CHECK();
   return 0;
@@ -940,12 +936,8 @@ int launch_wgrad(WgradArgs& a, const WPlan& w, hipStream_t stream) {
 template <int KT, int KH, int KW, int MB, int NB, int PCH>
 int launch_wgrad2(const Wgrad2Args& a, const WPlan& w, hipStream_t stream) {
   auto kern = conv_wgrad2_kernel<KT, KH, KW, MB, NB, PCH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(512), w.lds2, stream, a);
   COCLR_LAUNCH_CHECK();
   return 0;
@@ -996,21 +988,13 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
       const size_t lds = (size_t)2 * (big ? 256 : 128) * 64 * sizeof(float);
       if (big) {
         auto kern = conv_wgrad_pw_kernel<2, 2>;
-        static bool attr_done = false;
-        if (!attr_done) {
-          COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          attr_done = true;
-        }
+        static std::atomic<uint64_t> attr_done{0};
+        COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
         hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(512), lds, stream, a);
       } else {
         auto kern = conv_wgrad_pw_kernel<1, 1>;
-        static bool attr_done = false;
-        if (!attr_done) {
-          COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          attr_done = true;
-        }
+        static std::atomic<uint64_t> attr_done{0};
+        COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
         hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(512), lds, stream, a);
       }
       COCLR_LAUNCH_CHECK();
@@ -1025,13 +1009,8 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
       case 5: rc = launch_wgrad2<1, 1, 1, 1, 1, 2>(a, w, stream); break;
       case 9: {
         auto kern = conv_wgrad_stem_kernel<7, 7, 3, 20>;
-        static bool attr_done = false;
-        if (!attr_done) {
-          COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              160 * 1024));
-          attr_done = true;
-        }
+        static std::atomic<uint64_t> attr_done{0};
+        COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
         hipLaunchKernelGGL(kern, dim3(w.S2, 1, w.mt2), dim3(512), w.lds2, stream, a);
         COCLR_LAUNCH_CHECK();
         rc = 0;

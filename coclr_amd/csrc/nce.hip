@@ -185,6 +185,11 @@ momentum_update_kernel(const int64_t* __restrict__ table, float m, float one_min
 __global__ void queue_enqueue_kernel(float* queue, const float* __restrict__ keys, int D, int K,
                                      int BW, const int64_t* __restrict__ ptr) {
   const int p = (int)(*ptr);
+  // A pointer that is not a multiple of this batch (checkpoint resumed with another global batch)
+  // would run past the row / the buffer; the reference raises on the slice assignment
+  // (pretrain.py:93).  The host validates the pointer once per load; the kernel never writes
+  // outside [0, K) whatever it holds.
+  if (p < 0 || p + BW > K) return;
   const int total = D * BW;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int d = e / BW, j = e - d * BW;   // j fastest: contiguous writes along a queue row
@@ -193,8 +198,9 @@ __global__ void queue_enqueue_kernel(float* queue, const float* __restrict__ key
 }
 
 __global__ void queue_fill_i64_kernel(int64_t* q, const int64_t* __restrict__ vals, int64_t cval,
-                                      int BW, const int64_t* __restrict__ ptr) {
+                                      int K, int BW, const int64_t* __restrict__ ptr) {
   const int p = (int)(*ptr);
+  if (p < 0 || p + BW > K) return;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < BW; j += gridDim.x * blockDim.x)
     q[p + j] = vals ? vals[j] : cval;
 }
@@ -406,7 +412,7 @@ extern "C" int coclr_queue_fill_i64(int64_t* queue, const int64_t* vals, int64_t
                                     int BW, const int64_t* ptr, void* stream) {
   if (K <= 0 || BW <= 0 || BW > K) return COCLR_EINVAL;
   hipLaunchKernelGGL(queue_fill_i64_kernel, dim3(grid1d(BW)), dim3(256), 0, (hipStream_t)stream,
-                     queue, vals, const_val, BW, ptr);
+                     queue, vals, const_val, K, BW, ptr);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
@@ -424,12 +430,8 @@ extern "C" int coclr_positive_mask(const float* sim, const int64_t* src, const i
   if (topk > 0 && !sim) return COCLR_EINVAL;
   const size_t lds = topk > 0 ? (size_t)K * sizeof(float) : 0;
   if (lds > 150 * 1024) return COCLR_EINVAL;
-  static bool attr_done = false;
-  if (!attr_done) {
-    COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(positive_mask_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(positive_mask_kernel), 150 * 1024, attr_done));
   hipLaunchKernelGGL(positive_mask_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sim, src,
                      names, mask, K, topk);
   COCLR_LAUNCH_CHECK();

@@ -163,7 +163,11 @@ class Run:
         self.device = device
         self.save = save
         self.need_input_grad = need_input_grad
-        self.tape = []         # (closure, lane) in emission order
+        # (closure, lane) in emission order.  Closures take the run as their ARGUMENT and must not
+        # capture it: run -> tape -> closure -> run would be a cycle that only the cyclic gc frees,
+        # one backbone stage per collection (each stage's tape holds the previous stage's output,
+        # whose grad_fn owns that stage's run) -- GBs of activations parked behind gc's schedule.
+        self.tape = []
         self.cur_lane = None
         self._parent = None
         self._open = []
@@ -173,6 +177,13 @@ class Run:
         self.out = None
         self.plan = None       # PackPlan of the module being run
         self.batched = False   # the plan's launch has re-laid its operands for this pass
+        self._side_used = False
+        self._side_keep = []   # tensors read by side-stream kernels, released at join_side()
+        if device.type == "cuda" and device.index is not None and \
+                device.index != torch.cuda.current_device():
+            # kernels are enqueued on the CURRENT device's current stream (ops._stream)
+            raise RuntimeError("coclr_amd: tensors live on %s but the current device is cuda:%d; "
+                               "call torch.cuda.set_device first" % (device, torch.cuda.current_device()))
 
     def begin(self, module):
         """Attach the module's pack plan and replay it."""
@@ -249,7 +260,7 @@ class Run:
                     for st in started.values():
                         cur.wait_stream(st)
                     started = {}
-                fn()
+                fn(self)
             else:
                 st = started.get(lane)
                 if st is None:
@@ -257,7 +268,7 @@ class Run:
                     st.wait_stream(parent)
                     started[lane] = st
                 with torch.cuda.stream(st):
-                    fn()
+                    fn(self)
         if started:
             cur = torch.cuda.current_stream(self.device)
             for st in started.values():
@@ -277,15 +288,20 @@ class Run:
         if st is None:
             st = _SIDE[self.device] = torch.cuda.Stream(device=self.device)
         st.wait_stream(torch.cuda.current_stream(self.device))
-        for t in inputs:
-            t.record_stream(st)      # the allocator must not recycle it under the side kernels
+        # Everything the side kernels read (the gradient dy AND the saved activation x) stays
+        # referenced until join_side(): once a closure is popped its tensors would otherwise go
+        # back to the main stream's allocator pool and could be handed out again while a lagging
+        # weight-gradient kernel still reads them.  Holding the references is cheaper on the host
+        # than record_stream (no event queries at free time) and bounded by one backward pass.
+        self._side_keep.extend(inputs)
         self._side_used = True
         return st
 
     def join_side(self):
-        if getattr(self, "_side_used", False):
+        if self._side_used:
             torch.cuda.current_stream(self.device).wait_stream(_SIDE[self.device])
             self._side_used = False
+        self._side_keep = []
 
     # -- weight packing ------------------------------------------------------------
     def _packed_buffer(self, owner, tag, n, zero):
@@ -466,7 +482,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
         if n_index is not None and x_needs:
             raise NotImplementedError("coclr_amd: gathered conv input cannot require grad")
 
-        def backward():
+        def backward(run):
             dz = run.grad_of(out)
             dy = torch.empty_like(y)
             dgb = run.empty(2, Cout)
@@ -482,7 +498,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
             if bn.bias.requires_grad:
                 run.add_param_grad(bn.bias, dgb[1])
             if w.requires_grad:
-                with torch.cuda.stream(run.side_stream(dy)):
+                with torch.cuda.stream(run.side_stream(dy, xv)):
                     dw = torch.empty_like(w)
                     kk = w.shape[2] * w.shape[3] * w.shape[4]
                     for t, g in enumerate(geoms):
@@ -566,7 +582,7 @@ def pointwise_group(run, x, units):
     if run.save:
         x_needs = run.needs_grad(x)
 
-        def backward():
+        def backward(run):
             dy = torch.empty_like(y)
             for (conv, bn, _), out, (c0, C_, mean, invstd, scale, shift) in zip(units, outs, saved):
                 dgb = run.empty(2, C_)
@@ -579,7 +595,7 @@ def pointwise_group(run, x, units):
                 if bn.bias.requires_grad:
                     run.add_param_grad(bn.bias, dgb[1])
             if any(w.requires_grad for w in weights):
-                with torch.cuda.stream(run.side_stream(dy)):
+                with torch.cuda.stream(run.side_stream(dy, xv)):
                     dw = run.empty(Ccat, Cin, 1, 1, 1)
                     ws = run.empty(geom.wgrad_workspace())
                     ops.conv_wgrad(geom, xv, dy, dw, ws, Cin, 1, 0)
@@ -610,7 +626,7 @@ def max_pool(run, x, kernel, stride, padding):
     ops.maxpool_fwd(g, x.view(), y, idx)
     out = Val(y)
     if need:
-        def backward():
+        def backward(run):
             dx, acc = run.grad_target(x)
             ops.maxpool_bwd(g, run.grad_of(out), idx, dx, accumulate=acc)
         run.record(backward)
@@ -648,7 +664,7 @@ def self_gating(run, x, fc, out=None):
         out = Val(torch.empty_like(xv))
     ops.plane_scale(xv, wgt, None, out.view())
     if run.save:
-        def backward():
+        def backward(run):
             dout = run.grad_of(out)
             dwgt = run.empty(N, C_)
             ops.plane_dot(dout, xv, dwgt)
@@ -691,7 +707,12 @@ class EngineFn(torch.autograd.Function):
         ctx.params = params
         ctx.need_dx = need_dx
         out = run.out.view()
-        return out if out.is_contiguous() else out.contiguous()
+        # A FRESH tensor object: autograd stamps what we return with grad_fn, and grad_fn -> ctx
+        # -> run -> tape closures -> run.out.  Returning run.out's own tensor would close that
+        # into a reference cycle (tensor -> grad_fn -> ... -> same tensor) that Python's gc cannot
+        # see through, so a forward that is never followed by backward (main_coclr.py:403 skips
+        # loss.backward() until the queue is full) would leak its whole activation tape.
+        return out.detach() if out.is_contiguous() else out.contiguous()
 
     @staticmethod
     def backward(ctx, dout):

@@ -269,6 +269,25 @@ class InfoNCE(nn.Module):
         self.queue = nn.functional.normalize(self.queue, dim=0)
         self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
         self._momentum_table = None
+        self.__dict__["_ptr_checked_for"] = None    # global batch the loaded pointer was validated for
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        # a resumed queue_ptr must be re-validated against the batch it will be used with
+        self.__dict__["_ptr_checked_for"] = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _check_queue_ptr(self, batch_size):
+        """The reference fails on `queue[:, ptr:ptr+B] = keys.T` (ref :93) when a resumed pointer
+        does not fit the current global batch; the device-side pointer never reaches the host in
+        the steady state, so it is read ONCE per (construction | load_state_dict, batch size)."""
+        if self.__dict__.get("_ptr_checked_for") == batch_size:
+            return
+        ptr = int(self.queue_ptr)
+        if ptr % batch_size != 0 or ptr + batch_size > self.K or ptr < 0:
+            raise RuntimeError(
+                "coclr_amd: queue_ptr=%d does not fit a global batch of %d in a queue of %d "
+                "(checkpoint written with another batch size / world size?)" % (ptr, batch_size, self.K))
+        self.__dict__["_ptr_checked_for"] = batch_size
 
     # -- buffers: one flat allocation, one broadcast --------------------------------
     @property
@@ -301,6 +320,11 @@ class InfoNCE(nn.Module):
         self.__dict__["_flat_buffers"] = flat
 
     def _sync_buffers(self):
+        dev = self.queue.device
+        if dev.type == "cuda" and dev.index != torch.cuda.current_device():
+            # every kernel is enqueued on the current device's current stream (ops._stream)
+            raise RuntimeError("coclr_amd: model lives on %s but the current device is cuda:%d; "
+                               "call torch.cuda.set_device first" % (dev, torch.cuda.current_device()))
         flat = self.__dict__.get("_flat_buffers")
         if flat is None or flat.device != self.queue.device or \
                 self.queue.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr() or \
@@ -349,6 +373,7 @@ class InfoNCE(nn.Module):
         """keys_all: (B*world, dim) in global batch order."""
         batch_size = keys_all.shape[0]
         assert self.K % batch_size == 0  # for simplicity
+        self._check_queue_ptr(batch_size)
         ops.queue_enqueue(self.queue, keys_all.contiguous(), self.queue_ptr)
         for qbuf, vals, const in extra:
             ops.queue_fill_i64(qbuf, vals, const, batch_size, self.queue_ptr)
@@ -444,13 +469,28 @@ class InfoNCE(nn.Module):
         if params is None:
             params = encoder.__dict__["_coclr_plist"] = list(encoder.parameters())
         flat = self.__dict__.get("_flat_buffers")
+        # One cache entry per (encoder, BN mode, with/without the momentum prologue): toggling
+        # train()/eval() or no_grad switches between captured graphs instead of re-capturing.
+        key = (id(encoder), encoder.training, encoder[0].training, pre is not None)
+        # Everything a replay bakes in: shapes, every address the captured kernels read or write
+        # (encoder parameters, the flat buffer allocation, and -- for the momentum prologue -- the
+        # query parameters and m itself, which the kernel receives as constants).
         sig = (tuple(src.shape[1:]), int(n_index.shape[0]), src.dtype, dev, params[0].data_ptr(),
-               params[-1].data_ptr(), 0 if flat is None else flat.data_ptr(), encoder.training,
-               encoder[0].training, pre is not None)
+               params[-1].data_ptr(), 0 if flat is None else flat.data_ptr())
+        if pre is not None:
+            qps = self.encoder_q.__dict__.get("_coclr_plist")
+            if qps is None:
+                qps = self.encoder_q.__dict__["_coclr_plist"] = list(self.encoder_q.parameters())
+            sig += (float(self.m), qps[0].data_ptr(), qps[-1].data_ptr())
+        bns = encoder.__dict__.get("_coclr_bns")
+        if bns is None:
+            bns = encoder.__dict__["_coclr_bns"] = [
+                mod for mod in encoder.modules() if isinstance(mod, nn.modules.batchnorm._BatchNorm)]
+        sig += (hash(tuple((mod.momentum, mod.eps) for mod in bns)),)   # kernel constants too
         store = self.__dict__.setdefault("_graphs", {})
-        ent = store.get(id(encoder))
+        ent = store.get(key)
         if ent is None or ent["sig"] != sig:
-            ent = store[id(encoder)] = {"sig": sig, "calls": 0}
+            ent = store[key] = {"sig": sig, "calls": 0}
         if ent["calls"] < 1:                       # first call eager: one-time attribute calls etc.
             ent["calls"] += 1
             if pre is not None:
@@ -643,6 +683,7 @@ class CoCLR(InfoNCE):
     def _enqueue_coclr(self, keys_all, keys_second_all, vnames_all):
         batch_size = keys_all.shape[0]
         assert self.K % batch_size == 0  # for simplicity
+        self._check_queue_ptr(batch_size)
         ops.queue_enqueue(self.queue, keys_all.contiguous(), self.queue_ptr)
         ops.queue_enqueue(self.queue_second, keys_second_all.contiguous(), self.queue_ptr)
         ops.queue_fill_i64(self.queue_vname, vnames_all.contiguous(), 0, batch_size,

@@ -52,8 +52,6 @@ def _chk5(t, name):
 
 WINOGRAD = os.environ.get("COCLR_WINOGRAD", "1") != "0"
 WINOGRAD_HW = os.environ.get("COCLR_WINOGRAD_HW", "1") != "0"
-# "2": route the spatial form through the two-waves-per-SIMD kernel (experimental)
-WINOGRAD_HW_ALGO = 2 if os.environ.get("COCLR_WINOGRAD_HW", "1") == "2" else 1
 
 
 def winograd_ok(cin, k, s, p, d, lattice, odim=None):
@@ -108,8 +106,8 @@ class ConvGeom:
             tuple(lattice[2])
         # algo 1 = Winograd (see winograd_ok); the packed operand differs
         self.algo = int(algo)
-        if self.algo == 2 and self.k != (1, 3, 3):
-            raise ValueError("coclr_amd: algo 2 is a (1,3,3) kernel variant")
+        if self.algo not in (0, 1):
+            raise ValueError("coclr_amd: unknown convolution algorithm %d" % self.algo)
         if self.algo >= 1 and not winograd_ok(self.Cin, self.k, self.s, self.p, self.d, lattice,
                                               self.odim):
             raise ValueError("coclr_amd: Winograd needs a (3,1,1) or (1,3,3) stride-1 'same' stencil")
@@ -205,8 +203,7 @@ def conv_geom(N, Cin, Cout, idim, k, s, p):
             _GEOMS.clear()
         g = ConvGeom(N, Cin, Cout, idim, k, s, p)
         if winograd_pays(Cin, k, s, p, g.odim):
-            g = ConvGeom(N, Cin, Cout, idim, k, s, p,
-                         algo=WINOGRAD_HW_ALGO if tuple(k) == (1, 3, 3) else 1)
+            g = ConvGeom(N, Cin, Cout, idim, k, s, p, algo=1)
         _GEOMS[key] = g
     return g
 

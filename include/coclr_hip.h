@@ -57,10 +57,7 @@ typedef struct coclr_conv_desc {
                               operand made by coclr_conv_pack_weights(transpose | 2):
                               (3,1,1) stencil, stride 1, pad (1,0,0): F(2,3) along T, taps = 4;
                               (1,3,3) stencil, stride 1, pad (0,1,1), even Ho/Wo >= 4, dense
-                              destination, no n_index: F(2x2,3x3), taps = 16;
-                              2: as 1 for a (1,3,3) stencil, two-waves-per-SIMD kernel (same
-                              operand; experimental, not selected by the Python host unless
-                              COCLR_WINOGRAD_HW=2) */
+                              destination, no n_index: F(2x2,3x3), taps = 16 */
 } coclr_conv_desc;
 
 /* Number of fp32 elements of the packed-weight buffer for one conv. */

@@ -502,13 +502,8 @@ WINO_HW_CASES = [(2, 64, 192, (2, 32, 32)), (2, 192, 208, (4, 16, 16)), (3, 48, 
                  (2, 24, 64, (2, 12, 20)), (9, 40, 64, (3, 4, 4))]
 
 
-EXPERIMENTAL = os.environ.get("COCLR_TEST_EXPERIMENTAL", "0") == "1"
-
-
-@pytest.mark.parametrize("algo", [1, pytest.param(2, marks=pytest.mark.skipif(
-    not EXPERIMENTAL, reason="two-waves-per-SIMD kernel: opt-in (COCLR_TEST_EXPERIMENTAL=1)"))])
 @pytest.mark.parametrize("case", WINO_HW_CASES, ids=lambda c: "%d_%d_%d_%s" % c)
-def test_conv_spatial_winograd(case, algo):
+def test_conv_spatial_winograd(case, algo=1):
     """(1,3,3) stride-1 pad-1 convolutions through Winograd F(2x2,3x3) (algo = 1): forward with
     BatchNorm partial sums, accumulate form, fused affine+ReLU epilogue, and the data gradient --
     ragged channel counts, maps that are not a power of two, boxes spanning frames and samples."""
@@ -523,8 +518,7 @@ def test_conv_spatial_winograd(case, algo):
     ref.backward(dy)
     g = ops.ConvGeom(N, Cin, Cout, dims, k, s, p, algo=algo)   # conv_geom() keeps small maps direct
     assert g.dgrad().algo == algo
-    assert ops.conv_geom(N, Cin, Cout, dims, k, s, p).algo == (
-        ops.WINOGRAD_HW_ALGO if min(dims[1:]) >= 16 else 0)
+    assert ops.conv_geom(N, Cin, Cout, dims, k, s, p).algo == (1 if min(dims[1:]) >= 16 else 0)
     run = engine.Run(torch.device("cuda"), save=False)
     wd, xd, dyd = dev(w.detach()), dev(x.detach()), dev(dy)
     y = torch.full((N, Cout, *g.odim), float("nan"), device="cuda")

@@ -10,6 +10,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_layers.py "$@" > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace -f csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/${PMC_SCRIPT:-tools/bench_layers.py} "$@" > $OUT/p$i.log 2>&1
 done
 python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT

@@ -10,7 +10,7 @@ for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.cs
         c = d.setdefault(r["Counter_Name"], [0.0, 0])
         c[0] += float(r["Counter_Value"]); c[1] += 1
 for name, d in agg.items():
-    if not any(k in name for k in ("conv_", "bn_", "maxpool", "gemm", "wgrad")):
+    if not any(k in name for k in ("conv_", "bn_", "maxpool", "gemm", "wgrad", "nce_", "positive_mask", "adam", "loss", "stage")):
         continue
     print(name)
     for k, (s, n) in sorted(d.items()):
