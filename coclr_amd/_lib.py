@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -72,6 +72,14 @@ _SIGNATURES = {
     "coclr_sigmoid_bwd": [vp, vp, vp, i64, vp],
     "coclr_plane_scale": [vp, vp, vp, vp, i32, i32, i64, i64, i64, i32, vp],
     "coclr_plane_dot": [vp, vp, vp, i32, i32, i64, i64, i64, vp],
+    "coclr_adam_step": [vp, i32, vp, vp, vp, i32, f32, f32, vp],
+    "coclr_nce_loss_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "coclr_nce_loss_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "coclr_stage_clips": [vp, i32, vp, i32, i32, i32, i64, _P(f32), _P(f32), vp],
+    "coclr_colstats_workspace": [i32, i32, _P(i64)],
+    "coclr_bn1d_stats": [vp, vp, vp, i32, i32, vp],
+    "coclr_center_rows": [vp, vp, vp, i32, i32, vp],
+    "coclr_retrieval_hits": [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp],
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -6,10 +6,15 @@ OUT=../libcoclr_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in conv_igemm conv_wgrad bn pool nce version; do
+for f in conv_igemm conv_wgrad bn pool nce optim loss staging retrieval version; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || \
      [ conv_geom.h -nt build/$f.o ] || [ ../../include/coclr_hip.h -nt build/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    # optim / staging reproduce ATen's separately rounded elementwise arithmetic bit for bit: no
+    # fused multiply-add contraction there (HIP's default is -ffp-contract=fast, which the backend
+    # applies to packed fp32 operations even under `#pragma clang fp contract(off)`)
+    extra=""
+    if [ $f = optim ] || [ $f = staging ]; then extra="-ffp-contract=off"; fi
+    hipcc $FLAGS $extra -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done

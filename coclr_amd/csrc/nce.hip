@@ -4,7 +4,7 @@
 //     CoCLR cross-modal similarity (pretrain.py:405) and the 1x1x1 projection
 //     convs on pooled features (pretrain.py:52,54)
 //   * L2 normalise fwd/bwd (pretrain.py:154,167,380), l_pos (pretrain.py:175)
-//   * multi-tensor momentum update (pretrain.py:76-80)
+//   * (the multi-tensor momentum update, pretrain.py:76-80, lives in optim.hip)
 //   * FIFO queue enqueue with a device-resident pointer (pretrain.py:82-96,321-341)
 //   * per-row top-k mining + positive-mask build (pretrain.py:397-413, 267-269)
 //   * row gather for shuffle-BN (pretrain.py:124,143), ReLU, column sums
@@ -164,20 +164,6 @@ __global__ void lpos_bwd_kernel(const float* __restrict__ dlogits, const float* 
   }
 }
 
-// ---------------------------------------------------------------------------
-// multi-tensor momentum update: table[3*i..] = {dst ptr, src ptr, count}
-// dst = dst*m + src*(1-m), rounded as two products and one add (matches the
-// reference's p_k*m + p_q*(1-m) tensor expression, no FMA contraction).
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-momentum_update_kernel(const int64_t* __restrict__ table, float m, float one_minus_m) {
-  const int64_t* ent = table + 3 * (long)blockIdx.x;
-  float* dst = reinterpret_cast<float*>(ent[0]);
-  const float* src = reinterpret_cast<const float*>(ent[1]);
-  const int cnt = (int)ent[2];
-  for (int i = threadIdx.x; i < cnt; i += 256)
-    dst[i] = __fadd_rn(__fmul_rn(dst[i], m), __fmul_rn(src[i], one_minus_m));
-}
 
 // ---------------------------------------------------------------------------
 // queue[:, ptr:ptr+BW] = keys^T   (queue is [D][K], keys is [BW][D])
@@ -386,15 +372,6 @@ extern "C" int coclr_nce_logits_bwd(const float* dlogits, const float* k, const 
   if (rc) return rc;
   hipLaunchKernelGGL(lpos_bwd_kernel, dim3(grid1d((long)B * D)), dim3(256), 0, stream, dlogits, k,
                      dq, B, D, (long)(1 + K), inv_T);
-  COCLR_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int coclr_momentum_update(const int64_t* table, int nchunks, float m, float one_minus_m,
-                                     void* stream) {
-  if (nchunks <= 0) return COCLR_EINVAL;
-  hipLaunchKernelGGL(momentum_update_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
-                     table, m, one_minus_m);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.distributed as dist
 
 from .. import ops
+from .. import optim as _optim
 from ..backbone.select_backbone import select_backbone
 
 _CHUNK = 32768   # elements per workgroup of the momentum kernel
@@ -270,6 +271,7 @@ class InfoNCE(nn.Module):
         self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
         self._momentum_table = None
         self.__dict__["_ptr_checked_for"] = None    # global batch the loaded pointer was validated for
+        _optim.register_momentum_model(self)        # for coclr_amd.optim.Adam(fold_momentum=True)
 
     def _load_from_state_dict(self, *args, **kwargs):
         # a resumed queue_ptr must be re-validated against the batch it will be used with
@@ -366,6 +368,22 @@ class InfoNCE(nn.Module):
             self._build_momentum_table()
             mt = self._momentum_table
         ops.momentum_update(mt[1], mt[2], float(self.m), float(1. - self.m), pairs=(mt[4], mt[3]))
+
+    def _momentum_pre(self, in_train_mode):
+        """The momentum update to run in front of the key encoder, or None: outside training
+        (ref :157-160), or when coclr_amd.optim.Adam(fold_momentum=True) has already applied this
+        forward's update at the end of its step (same arithmetic, same operands)."""
+        if not in_train_mode:
+            return None
+        folded = self.__dict__.pop("_momentum_folded", None)
+        if folded is None:
+            return self._momentum_update_key_encoder
+        if folded != float(self.m):
+            raise RuntimeError(
+                "coclr_amd: the momentum coefficient changed (%.6f -> %.6f) after an optimizer "
+                "step that had folded the key-encoder update; use fold_momentum=False with a "
+                "per-iteration momentum schedule" % (folded, float(self.m)))
+        return None
 
     # -- queue ---------------------------------------------------------------------
     @torch.no_grad()
@@ -600,7 +618,7 @@ class InfoNCE(nn.Module):
         # together instead of the key encoder waiting for the host to enqueue the query one
         with torch.no_grad(), torch.cuda.stream(side):
             k, k_all = self._encode_keys(
-                x2, pre=self._momentum_update_key_encoder if in_train_mode else None)
+                x2, pre=self._momentum_pre(in_train_mode))
         q = self._encode(self.encoder_q, x1)
         assert q.requires_grad == in_train_mode
         self._join(side)
@@ -641,7 +659,7 @@ class UberNCE(InfoNCE):
         # together instead of the key encoder waiting for the host to enqueue the query one
         with torch.no_grad(), torch.cuda.stream(side):
             k, k_all = self._encode_keys(
-                x2, pre=self._momentum_update_key_encoder if in_train_mode else None)
+                x2, pre=self._momentum_pre(in_train_mode))
         q = self._encode(self.encoder_q, x1)
         assert q.requires_grad == in_train_mode
         self._join(side)
@@ -710,7 +728,7 @@ class CoCLR(InfoNCE):
         in_train_mode = self._query_requires_grad(x1)    # == q.requires_grad (ref :157)
         with torch.no_grad(), torch.cuda.stream(side):
             k, k_all = self._encode_keys(
-                x2, pre=self._momentum_update_key_encoder if in_train_mode else None)
+                x2, pre=self._momentum_pre(in_train_mode))
             # second view: frozen sampler (eval-mode BN in the reference's training loop),
             # not shuffled
             ident = self.__dict__.get("_ident_idx")

@@ -497,3 +497,74 @@ def plane_dot(a, b, out):
     N, C_, T, H, W = a.shape
     _lib.check(_L().coclr_plane_dot(_p(a), _p(b), _p(out), N, C_, T * H * W, _chk5(a, "a"),
                                     _chk5(b, "b"), _stream()), "plane_dot")
+
+
+# ---- training-loop neighbours: optimiser, loss epilogue, input staging -------------------
+
+def adam_step(table, nchunks, hyper, steps, groups, ngroups, mom_m=0.0, mom_1m=0.0, keep=None):
+    """One multi-tensor Adam launch (+ folded momentum-encoder update where the table names a key
+    parameter).  `keep`: the tensors the table points at, referenced while the launch is queued."""
+    _lib.check(_L().coclr_adam_step(_p(table, torch.int64), nchunks, _p(hyper, torch.float64), _p(steps),
+                                    _p(groups, torch.int32), ngroups, mom_m, mom_1m, _stream()),
+               "adam_step")
+
+
+def nce_loss_fwd(logits, mask, target, rowstats, flags, scalars, mode, drop_self=False, k1=1, k2=5):
+    B, N1 = logits.shape
+    _lib.check(_L().coclr_nce_loss_fwd(
+        _p(logits), _p(mask, torch.uint8), _p(target, torch.int64), _p(rowstats),
+        _p(flags, torch.uint8), _p(scalars), B, N1, mode, int(drop_self), k1, k2, _stream()),
+        "nce_loss_fwd")
+
+
+def nce_loss_bwd(logits, mask, target, rowstats, flags, dloss, dlogits, mode):
+    B, N1 = logits.shape
+    _lib.check(_L().coclr_nce_loss_bwd(
+        _p(logits), _p(mask, torch.uint8), _p(target, torch.int64), _p(rowstats),
+        _p(flags, torch.uint8), _p(dloss), _p(dlogits), B, N1, mode, _stream()), "nce_loss_bwd")
+
+
+def stage_clips(frames, out, S, mean, std):
+    """frames (B, C, S*T, H, W) uint8 or fp32 in [0,1] -> out (B, S, C, T, H, W) fp32."""
+    B, Cc = frames.shape[0], frames.shape[1]
+    thw = frames[0, 0].numel() // S
+    if frames.dtype == torch.uint8:
+        src, u8 = _p(frames, torch.uint8), 1
+    else:
+        src, u8 = _p(frames), 0
+    m = (C.c_float * Cc)(*[float(v) for v in mean])
+    s = (C.c_float * Cc)(*[float(v) for v in std])
+    _lib.check(_L().coclr_stage_clips(src, u8, _p(out), B, Cc, S, thw, m, s, _stream()),
+               "stage_clips")
+
+
+# ---- evaluation consumers ---------------------------------------------------------------
+
+def colstats_workspace(rows, cols):
+    out = C.c_int64(0)
+    _lib.check(_L().coclr_colstats_workspace(rows, cols, C.byref(out)), "colstats_workspace")
+    return out.value
+
+
+def bn1d_stats(x, stats, workspace):
+    rows, cols = x.shape
+    _lib.check(_L().coclr_bn1d_stats(_p(x), _p(stats), _p(workspace), rows, cols, _stream()),
+               "bn1d_stats")
+
+
+def center_rows(x, out, workspace):
+    rows, cols = x.shape
+    _lib.check(_L().coclr_center_rows(_p(x), _p(out), _p(workspace), rows, cols, _stream()),
+               "center_rows")
+
+
+def retrieval_hits(sim, train_label, test_label, ks, hits, topidx=None):
+    """ks: int32 device tensor, ascending; hits fp32 (B, len(ks)); topidx int32 (B, ks[-1])."""
+    B, N = sim.shape
+    if topidx is None:
+        raise ValueError("coclr_amd: retrieval_hits needs the topidx buffer (B, kmax)")
+    kmax = int(topidx.shape[1])
+    _lib.check(_L().coclr_retrieval_hits(
+        _p(sim), _p(train_label, torch.int64), _p(test_label, torch.int64), _p(ks, torch.int32),
+        ks.shape[0], _p(hits), _p(topidx, torch.int32), B, N, kmax, _stream()),
+        "retrieval_hits")

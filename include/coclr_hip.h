@@ -253,6 +253,72 @@ int coclr_plane_scale(const float* a, const float* gain, const float* bias, floa
 int coclr_plane_dot(const float* a, const float* b, float* out, int N, int C, int64_t S,
                     int64_t a_nstride, int64_t b_nstride, void* stream);
 
+/* ------------------------------------------------------------------------ */
+/* Training-loop neighbours of the model: optimiser step,     */
+/* loss + accuracy epilogue, input staging                                   */
+/* ------------------------------------------------------------------------ */
+
+/* torch.optim.Adam.step() over the launch scripts' one-group-per-tensor parameter list
+ * (main_nce.py:190-200,331; main_coclr.py:213,406) as ONE launch, operation-for-operation the
+ * arithmetic of torch.optim.Adam (amsgrad=False, maximize=False, L2 weight decay).
+ *   table  int64[nchunks][8] on device: {param, grad, exp_avg, exp_avg_sq, key_param or 0,
+ *          count (<= 65536 elements of the tensor), group index, 0}
+ *   hyper  double[.][8] on device, one row per group: {lr, beta1, beta2, eps, weight_decay, 0,0,0}
+ *          (doubles: torch forms 1-beta and beta**t from Python floats)
+ *   steps  float[.] on device, one per group: number of steps taken so far; read as t = steps+1
+ *          for the bias corrections, then incremented for the `ngroups` groups listed in `groups`
+ * key_param != 0 folds the momentum-encoder update of model/pretrain.py:76-80 into the pass:
+ *   key = key*mom_m + param_new*mom_1m  (exactly what the next forward would compute). */
+int coclr_adam_step(const int64_t* table, int nchunks, const double* hyper, float* steps,
+                    const int32_t* groups, int ngroups, float mom_m, float mom_1m, void* stream);
+
+/* Loss + accuracy over logits[B][N1] in one pass, results as device scalars:
+ *   mode 0  nn.CrossEntropyLoss(logits, target)                         (main_nce.py:315)
+ *   mode 1  multi_nce_loss: -log(sum_j softmax_j*mask_j)                (main_coclr.py:343-346);
+ *           drop_self: column 0 is left out of a row's positives when the row has others
+ *           (the mask_clone[mask_sum!=1, 0] = 0 branch, main_coclr.py:384-389)
+ *   mode 2  -(sum_j log_softmax_j*mask_j) / sum_j mask_j                (main_nce.py:322)
+ * scalars[5] = batch means of {loss, hit@k1, hit@k2, self-hit@k1, self-hit@k2}: hit@k = one of the
+ * row's positives is among its k largest logits (calc_topk_accuracy / calc_mask_accuracy,
+ * utils/utils.py:52-85), self-hit@k the same for column 0 alone (main_coclr.py:392).
+ * rowstats float[B][8] and flags uint8[B] carry what the backward needs.  mask: bytes, [B][N1]. */
+int coclr_nce_loss_fwd(const float* logits, const uint8_t* mask, const int64_t* target,
+                       float* rowstats, uint8_t* flags, float* scalars, int B, int N1, int mode,
+                       int drop_self, int k1, int k2, void* stream);
+/* dlogits = dloss[0]/B * (softmax - positives' weights); dloss is a DEVICE scalar. */
+int coclr_nce_loss_bwd(const float* logits, const uint8_t* mask, const int64_t* target,
+                       const float* rowstats, const uint8_t* flags, const float* dloss,
+                       float* dlogits, int B, int N1, int mode, void* stream);
+
+/* Loader frames -> model input in one pass (main_nce.py:207-209,299-302; utils/transforms.py:57-63;
+ * model/pretrain.py:149-150): frames[B][C][S][THW] (uint8 when from_u8, else fp32 in [0,1]) ->
+ * out[B][S][C][THW] fp32 = ((x / 255 if uint8) - mean[c]) / std[c].  THW = seq_len*H*W; mean / std
+ * are HOST arrays of C floats read at call time. */
+int coclr_stage_clips(const void* frames, int from_u8, float* out, int B, int C, int S, int64_t THW,
+                      const float* mean, const float* std, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Evaluation consumers (model/classifier.py:47-61; eval/main_classifier.py) */
+/* ------------------------------------------------------------------------ */
+
+/* fp32 workspace elements for the two column-statistics entry points below. */
+int coclr_colstats_workspace(int rows, int cols, int64_t* elems);
+/* BatchNorm1d batch statistics of pooled features x[rows][cols] (final_bn, classifier.py:34,56)
+ * as stats[2][cols] = {sum, sum of squares}: the layout coclr_bn_finalize takes with ntiles=1. */
+int coclr_bn1d_stats(const float* x, float* stats, float* workspace, int rows, int cols,
+                     void* stream);
+/* out = x - x.mean(0) (eval/main_classifier.py:690-691). */
+int coclr_center_rows(const float* x, float* out, float* workspace, int rows, int cols,
+                      void* stream);
+/* Nearest-neighbour retrieval (eval/main_classifier.py:699-703): for every row of sim[B][N] the
+ * kmax most similar columns in order (value descending, column ascending on ties);
+ * hits[b][i] = 1.0 if any(train_label[top ks[i] columns] == test_label[b]) else 0.0 (fp32, so
+ * coclr_colsum gives the accuracies); ks ascending, ks[nk-1] ==
+ * kmax.  topidx (optional) int32[B][kmax] receives the selected columns. */
+int coclr_retrieval_hits(const float* sim, const int64_t* train_label, const int64_t* test_label,
+                         const int32_t* ks, int nk, float* hits, int32_t* topidx, int B, int N,
+                         int kmax, void* stream);
+
 /* Library/ABI version, bumped when a signature changes. */
 int coclr_abi_version(void);
 

@@ -306,3 +306,106 @@ def training_state(sd, requires_grad_prefix="encoder_q."):
         if ident is not None:
             memo[ident] = v
     return out
+
+
+# ------------------------------------------------------------------------------------
+# Neighbours of the model in the training / evaluation loops.  Pinned by
+# tests/golden/next_*.pt, generated by oracle/make_golden_next.py from the reference's own
+# functions where they are importable (utils/utils.py, utils/transforms.py, model/classifier.py,
+# main_coclr.py::multi_nce_loss) and from torch.optim.Adam itself.
+# ------------------------------------------------------------------------------------
+
+def masked_nce_loss_drop_self(logits, mask):
+    """main_coclr.py:384-389, the branch taken 90 % of the time: positives other than the clip's
+    own key exist -> leave column 0 out of that row's loss."""
+    mask_clone = mask.clone()
+    mask_clone[mask.sum(1) != 1, 0] = 0
+    return multi_nce_loss(logits, mask_clone)
+
+
+def calc_topk_accuracy(output, target, topk=(1,)):
+    """utils/utils.py:52-69."""
+    maxk = max(topk)
+    batch_size = target.size(0)
+    _, pred = output.topk(maxk, 1, True, True)
+    pred = pred.t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0) * (1 / batch_size) for k in topk]
+
+
+def calc_mask_accuracy(output, target_mask, topk=(1,)):
+    """utils/utils.py:71-85."""
+    maxk = max(topk)
+    _, pred = output.topk(maxk, 1, True, True)
+    zeros = torch.zeros_like(target_mask).long()
+    pred_mask = torch.zeros_like(target_mask).long()
+    res = []
+    for k in range(maxk):
+        onehot = zeros.scatter(1, pred[:, k].unsqueeze(1), 1)
+        pred_mask = onehot + pred_mask
+        if k + 1 in topk:
+            res.append(((pred_mask * target_mask).sum(1) >= 1).float().mean(0))
+    return res
+
+
+def tr(frames, num_seq, seq_len, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """Input staging: ToTensor's /255 when the frames are uint8 (utils/transforms.py:49-51 /
+    torchvision ToTensor), T.Normalize(mean, std, channel=1) (utils/transforms.py:57-63 via
+    main_nce.py:207-209) and the view/transpose/contiguous of main_nce.py:299-302."""
+    x = frames.to(torch.float32) / 255 if frames.dtype == torch.uint8 else frames
+    shape = [1] * x.dim()
+    shape[1] = -1
+    x = (x - torch.as_tensor(mean).reshape(shape)) / torch.as_tensor(std).reshape(shape)
+    B = x.size(0)
+    return x.view(B, 3, num_seq, seq_len, x.shape[-2], x.shape[-1]).transpose(1, 2).contiguous()
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr, beta1, beta2, eps, weight_decay):
+    """torch.optim.Adam (amsgrad=False, maximize=False) as main_nce.py:200,331 uses it -- the
+    arithmetic lives in the un-vendored dependency (PyTorch, torch/optim/adam.py
+    `_single_tensor_adam`); restated here in float64 as the tolerance anchor and pinned against
+    torch.optim.Adam itself by tests/test_oracle_golden.py.  In place; `steps` is a list of ints."""
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+        steps[i] += 1
+        t = steps[i]
+        if weight_decay != 0:
+            g = g + weight_decay * p
+        m.mul_(beta1).add_(g, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** t, 1 - beta2 ** t
+        denom = v.sqrt() / (bc2 ** 0.5) + eps
+        p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def linear_classifier_forward(sd, network, block, training, use_l2_norm=False, use_final_bn=False,
+                              fc_key="final_fc.1"):
+    """LinearClassifier.forward without dropout noise (model/classifier.py:47-61): backbone ->
+    global average pool -> [L2 normalise] -> [BatchNorm1d] -> Linear.  fc_key is 'final_fc.1'
+    with the Dropout module in front (classifier.py:39-41), 'final_fc.0' without (:43-44)."""
+    feat = backbone_forward(network, sd, "backbone.", block, training)
+    feat = F.adaptive_avg_pool3d(feat, (1, 1, 1)).view(block.shape[0], -1)
+    if use_l2_norm:
+        feat = F.normalize(feat, p=2, dim=1)
+    x = feat
+    if use_final_bn:
+        if training:
+            sd["final_bn.num_batches_tracked"] += 1
+        x = F.batch_norm(x, sd["final_bn.running_mean"], sd["final_bn.running_var"],
+                         sd["final_bn.weight"], sd["final_bn.bias"], training, BN_MOMENTUM, BN_EPS)
+    logit = F.linear(x, sd[fc_key + ".weight"], sd[fc_key + ".bias"])
+    return logit, feat
+
+
+def nn_retrieval(test_feature, test_label, train_feature, train_label, ks=(1, 5, 10, 20, 50)):
+    """eval/main_classifier.py:686-706 (inline code of the retrieval test, not a function there):
+    centre, L2-normalise, dot product, k-NN label match.  Returns (accuracies, sim)."""
+    test_feature = test_feature - test_feature.mean(dim=0, keepdim=True)
+    train_feature = train_feature - train_feature.mean(dim=0, keepdim=True)
+    test_feature = F.normalize(test_feature, p=2, dim=1)
+    train_feature = F.normalize(train_feature, p=2, dim=1)
+    sim = test_feature.matmul(train_feature.t())
+    acc = []
+    for k in ks:
+        topkval, topkidx = torch.topk(sim, k, dim=1)
+        acc.append(torch.any(train_label[topkidx] == test_label.unsqueeze(1), dim=1).float().mean().item())
+    return acc, sim

@@ -345,6 +345,90 @@ def plane_dot(a, b, out):
     out.copy_((a * b).sum((2, 3, 4)))
 
 
+# ---- training-loop neighbours / evaluation consumers (host-logic doubles) -----------------
+
+def nce_loss_fwd(logits, mask, target, rowstats, flags, scalars, mode, drop_self=False, k1=1, k2=5):
+    B, N1 = logits.shape
+    lg = logits.detach().double()
+    lse = torch.logsumexp(lg, 1)
+    if mode == 0:
+        pos = torch.zeros(B, N1, dtype=torch.bool)
+        pos[torch.arange(B), target] = True
+    else:
+        pos = mask.bool()
+    eff = pos.clone()
+    drop = torch.zeros(B, dtype=torch.bool)
+    if mode == 1 and drop_self:
+        drop = (pos.sum(1) != 1) & pos[:, 0]
+        eff[drop, 0] = False
+    neg_inf = torch.full_like(lg, -float("inf"))
+    if mode == 2:
+        n = eff.sum(1).double()
+        loss = lse - (lg * eff).sum(1) / n
+        aux = n
+    else:
+        lsp = torch.logsumexp(torch.where(eff, lg, neg_inf), 1)
+        loss = lse - lsp
+        aux = lsp
+    pmax = torch.where(pos, lg, neg_inf).max(1).values
+    cgp = (lg > pmax[:, None]).sum(1)
+    cg0 = (lg > lg[:, :1]).sum(1)
+    rowstats[:, 0] = loss.float(); rowstats[:, 1] = lse.float(); rowstats[:, 2] = aux.float()
+    rowstats[:, 3] = (cgp < k1).float(); rowstats[:, 4] = (cgp < k2).float()
+    rowstats[:, 5] = (cg0 < k1).float(); rowstats[:, 6] = (cg0 < k2).float()
+    rowstats[:, 7] = lg.max(1).values.float()
+    flags.copy_(drop.to(torch.uint8))
+    scalars.copy_(rowstats[:, [0, 3, 4, 5, 6]].double().mean(0).float())
+
+
+def nce_loss_bwd(logits, mask, target, rowstats, flags, dloss, dlogits, mode):
+    B, N1 = logits.shape
+    lg = logits.detach()
+    sm = torch.exp(lg - rowstats[:, 1:2])
+    if mode == 0:
+        w = torch.zeros_like(lg)
+        w[torch.arange(B), target] = 1.0
+    else:
+        eff = mask.bool().clone()
+        eff[flags.bool(), 0] = False
+        w = torch.exp(lg - rowstats[:, 2:3]) * eff if mode == 1 else eff.float() / rowstats[:, 2:3]
+    dlogits.copy_((sm - w) * (dloss.reshape(()) / B))
+
+
+def stage_clips(frames, out, S, mean, std):
+    B, C_ = frames.shape[0], frames.shape[1]
+    x = frames.to(torch.float32) / 255 if frames.dtype == torch.uint8 else frames
+    m = torch.tensor(list(mean), dtype=torch.float32).view(1, C_, 1, 1, 1)
+    s = torch.tensor(list(std), dtype=torch.float32).view(1, C_, 1, 1, 1)
+    x = (x - m) / s
+    T = frames.shape[2] // S
+    out.copy_(x.view(B, C_, S, T, *frames.shape[3:]).transpose(1, 2))
+
+
+def colstats_workspace(rows, cols):
+    return 2 * min(rows, 64) * cols
+
+
+def bn1d_stats(x, stats, workspace):
+    C_ = x.shape[1]
+    stats[:C_] = x.double().sum(0).float()
+    stats[C_:] = (x.double() ** 2).sum(0).float()
+
+
+def center_rows(x, out, workspace):
+    out.copy_(x - x.mean(0, keepdim=True))
+
+
+def retrieval_hits(sim, train_label, test_label, ks, hits, topidx=None):
+    kmax = topidx.shape[1]
+    _, idx = torch.sort(sim, dim=1, descending=True, stable=True)
+    idx = idx[:, :kmax]
+    topidx.copy_(idx.to(torch.int32))
+    match = train_label[idx] == test_label[:, None]
+    for i, k in enumerate(ks.tolist()):
+        hits[:, i] = match[:, :k].any(1).float()
+
+
 _NAMES = [n for n, v in list(globals().items())
           if callable(v) and not n.startswith("_") and hasattr(ops, n) and n not in ("F",)]
 

@@ -7,7 +7,10 @@ import torch
 
 from oracle import coclr_oracle as orc
 
+import os
+
 pytestmark = pytest.mark.gpu
+VERBOSE = os.environ.get("COCLR_TEST_VERBOSE", "0") == "1"
 
 
 def rel(got, ref):
@@ -41,7 +44,7 @@ def _oracle_run(module_sd, oracle_fn, x, dout, dtype, input_grad):
 
 
 def check_module(module, oracle_fn, x, train=True, tol=1e-3, input_grad=True, factor=8.0,
-                 floor=2e-3):
+                 floor=2e-3, per_tensor=False):
     """Forward+backward `module` on the GPU vs oracle_fn(sd, "m", x) on the CPU with identical
     state.  Forward / running statistics: fixed 1e-3.  Gradients: the product must be as
     close to a float64 evaluation as the fp32 CPU evaluation is, because ReLU/max-pool
@@ -71,6 +74,8 @@ def check_module(module, oracle_fn, x, train=True, tol=1e-3, input_grad=True, fa
         assert e_got <= 0.3, "%s: err vs fp64 %.3e (fp32 CPU: %.3e)" % (what, e_got, e_ref)
         got_errs.append(e_got)
         ref_errs.append(e_ref)
+        if VERBOSE:
+            print("   %-44s err vs fp64 %.3e   (fp32 CPU %.3e)" % (what, e_got, e_ref))
         return e_got, e_ref
 
     worst = ("", 0.0, 0.0)
@@ -91,12 +96,29 @@ def check_module(module, oracle_fn, x, train=True, tol=1e-3, input_grad=True, fa
     g, r = torch.tensor(got_errs), torch.tensor(ref_errs)
     n = len(got_errs)
     factor_q = 3.0 if n >= 20 else factor
-    for q in (0.5, 0.9):
+    for q in ((0.5,) if per_tensor else (0.5, 0.9)):
         gq, rq = float(torch.quantile(g, q)), float(torch.quantile(r, q))
         assert gq <= factor_q * rq + floor, \
             "grad err quantile %.1f: %.3e vs fp32 CPU's own %.3e" % (q, gq, rq)
     assert float(g.mean()) <= factor_q * float(r.mean()) + floor, \
         "mean grad err vs fp64 %.3e, fp32 CPU's own %.3e" % (float(g.mean()), float(r.mean()))
+    if per_tensor:
+        # Well-conditioned cases (>= 512 values per BatchNorm channel): EVERY tensor is held, not
+        # just the distribution -- no tensor beyond 2e-2 of the float64 gradient and at least 90 %
+        # of them within max(3 x the fp32 CPU evaluation's own error, 5e-3), so that a wrong
+        # weight-gradient path of a single layer (a 5 % error is 5e-2) cannot hide behind the
+        # others.  Why not 1e-6 like the kernels themselves (profiles/r02_numerics_probe.txt: every
+        # conv / BatchNorm kernel is within 7e-6 of float64 elementwise, like ATen's CPU kernels):
+        # ONE ReLU decision taken differently -- an activation within fp32 round-off of zero, about
+        # one per 1.5 M elements -- moves the bias gradient of its channel by one element of a
+        # ~2048..8192-term sum, i.e. 2e-3..1e-2 of the tensor maximum, and every tensor upstream of
+        # it with it (observed signature: exact zeros below the flipped layer, ~2e-3 above).
+        ok = (g <= torch.maximum(3.0 * r, torch.tensor(5e-3))).float().mean()
+        print("per-tensor gradient errors vs fp64: max %.2e median %.2e (fp32 CPU: max %.2e), "
+              "%.0f %% within bound over %d tensors" % (float(g.max()), float(g.median()),
+                                                      float(r.max()), 100 * float(ok), n))
+        assert float(g.max()) <= 2e-2, "worst tensor %s: %.3e (fp32 CPU: %.3e)" % worst
+        assert float(ok) >= 0.90, "only %.0f %% of the tensors within max(3x CPU, 5e-3)" % (100 * float(ok))
     if train:
         for k, v in module.state_dict().items():
             if k.endswith("running_mean") or k.endswith("running_var"):
@@ -112,15 +134,15 @@ def test_basic_and_separable_conv_units():
     m = BasicConv3d(24, 40, kernel_size=1, stride=1)
     randomise(m, 1)
     x = torch.randn(4, 24, 4, 8, 8)
-    check_module(m, lambda sd, xx: orc.basic_conv3d(sd, "m", xx, True), x)
+    check_module(m, lambda sd, xx: orc.basic_conv3d(sd, "m", xx, True), x, per_tensor=True)
     m = STConv3d(3, 64, kernel_size=7, stride=2, padding=3)
     randomise(m, 2)
     x = torch.randn(2, 3, 8, 32, 32)
-    check_module(m, lambda sd, xx: orc.st_conv3d(sd, "m", xx, True, 2, 3), x)
+    check_module(m, lambda sd, xx: orc.st_conv3d(sd, "m", xx, True, 2, 3), x, per_tensor=True)
     m = STConv3d(32, 48, kernel_size=3, stride=1, padding=1)
     randomise(m, 3)
     x = torch.randn(3, 32, 4, 8, 8)
-    check_module(m, lambda sd, xx: orc.st_conv3d(sd, "m", xx, True, 1, 1), x)
+    check_module(m, lambda sd, xx: orc.st_conv3d(sd, "m", xx, True, 1, 1), x, per_tensor=True)
 
 
 @pytest.mark.parametrize("gating", [False, True])
@@ -131,7 +153,27 @@ def test_sep_inception_block(gating):
     randomise(m, 4)
     x = torch.relu(torch.randn(4, 48, 4, 8, 8))      # post-ReLU-like input (ties for the pool)
     # oracle keys: "<pre>.branch0.0..." -> strip the leading dot by using pre="m" then renaming
-    check_module(m, lambda sd, xx: orc.sep_inception(sd, "m", xx, True, gating), x)
+    check_module(m, lambda sd, xx: orc.sep_inception(sd, "m", xx, True, gating), x, per_tensor=True)
+
+
+def test_s3d_stages_per_tensor_gradients():
+    """Stages 2 and 3 of S3D at their real widths (Conv_2b/2c; MaxPool_3a + Mixed_3b + Mixed_3c,
+    backbone/s3dg.py:151-164) with >= 2048 values per BatchNorm channel: every one of their 54
+    parameter tensors individually within bound -- direct, Winograd (spatial and temporal), fused
+    pointwise heads, pooling, gradient accumulation over fan-out, all wgrad kernels."""
+    import torch.nn.functional as F
+    from backbone.s3dg import S3D
+    torch.manual_seed(0)
+    net = S3D()
+    randomise(net, 8)
+    x = torch.relu(torch.randn(4, 64, 8, 32, 32))
+    check_module(net.block2, lambda sd, xx: orc.st_conv3d(
+        sd, "m.2", orc.basic_conv3d(sd, "m.1", F.max_pool3d(xx, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                                    True), True, 1, 1), x, per_tensor=True)
+    x = torch.relu(torch.randn(4, 192, 8, 32, 32))
+    check_module(net.block3, lambda sd, xx: orc.sep_inception(
+        sd, "m.2", orc.sep_inception(sd, "m.1", F.max_pool3d(xx, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                                     True, False), True, False), x, per_tensor=True)
 
 
 def test_eval_mode_units_fold_bn_and_support_grad():

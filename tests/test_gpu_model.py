@@ -190,7 +190,8 @@ def test_graph_replay_matches_eager():
                                                          pre=m._momentum_update_key_encoder).clone())
         finally:
             product._GRAPHS = True
-    assert "graph" in models[0].__dict__["_graphs"][id(models[0].encoder_k)]
+    assert any("graph" in ent for key, ent in models[0].__dict__["_graphs"].items()
+               if key[0] == id(models[0].encoder_k))
     for a, b in zip(*keys):
         assert torch.equal(a, b)
     sd_g, sd_e = models[0].state_dict(), models[1].state_dict()

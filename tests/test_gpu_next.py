@@ -1,0 +1,331 @@
+"""GPU parity of the loop-neighbour kernels through the C ABI:
+optimiser step (csrc/optim.hip), loss + accuracy epilogue (csrc/loss.hip), input staging
+(csrc/staging.hip), LinearClassifier head and NN retrieval (csrc/retrieval.hip) -- against the
+fixtures recorded from the reference (tests/golden/next_*.pt) and against the CPU oracle at the
+benchmark sizes.  Bars: bit-exact for bytes / indices / hit counts / the staging arithmetic /
+the folded momentum update; 1e-6 relative for the loss and the Adam trajectory (the north star's
+1e-3 applies to model outputs; these are elementwise fp32 formulas)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _cases import check_close, load_golden
+from oracle import coclr_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- optimiser -------------------------------------------------------------------------------
+
+def test_adam_matches_torch_per_tensor_groups():
+    """main_nce.py:190-200,331: one param group per tensor, Adam(lr 1e-3, wd 1e-5), three steps."""
+    from coclr_amd import optim as O
+    g = load_golden("next_adam")
+    ps = [p.clone().cuda().requires_grad_(True) for p in g["p0"]]
+    frozen = torch.randn(7, device="cuda", requires_grad=True)          # never receives a gradient
+    opt = O.Adam([{"params": p} for p in ps] + [{"params": frozen}], lr=g["lr"], weight_decay=g["wd"])
+    f0 = frozen.detach().clone()
+    for step in range(3):
+        for p, gr in zip(ps, g["grads"][step]):
+            p.grad = gr.clone().cuda()
+        opt.step()
+        assert opt._plan is not None, "the HIP path must be the one that ran"
+        for p, ref in zip(ps, g["after"][step]):
+            check_close(p, ref, 1e-6, "adam step %d" % step)
+        opt.zero_grad(set_to_none=True)
+    assert torch.equal(frozen.detach(), f0) and len(opt.state[frozen]) == 0
+    # state in torch's format, loadable by torch's own Adam, and resumable by ours
+    sd = opt.state_dict()
+    assert float(sd["state"][0]["step"]) == 3.0
+    ref_ps = [p.clone().requires_grad_(True) for p in g["p0"]]
+    ref = O._TorchAdam([{"params": p} for p in ref_ps], lr=g["lr"], weight_decay=g["wd"])
+    for step in range(3):
+        for p, gr in zip(ref_ps, g["grads"][step]):
+            p.grad = gr.clone()
+        ref.step()
+    for i in range(len(ps)):
+        check_close(sd["state"][i]["exp_avg"], ref.state[ref_ps[i]]["exp_avg"], 1e-6, "exp_avg")
+        check_close(sd["state"][i]["exp_avg_sq"], ref.state[ref_ps[i]]["exp_avg_sq"], 1e-6, "exp_avg_sq")
+    # a learning-rate change (main_nce.py:adjust_learning_rate style) and a resumed optimiser
+    opt2 = O.Adam([{"params": p} for p in ps] + [{"params": frozen}], lr=g["lr"], weight_decay=g["wd"])
+    opt2.load_state_dict(sd)
+    for grp in list(opt2.param_groups) + list(ref.param_groups):
+        grp["lr"] = 3e-4
+    gen = torch.Generator().manual_seed(5)
+    for p, rp in zip(ps, ref_ps):
+        gr = torch.randn(rp.shape, generator=gen) * 0.01
+        p.grad, rp.grad = gr.cuda(), gr.clone()
+    opt2.step()
+    ref.step()
+    for p, rp in zip(ps, ref_ps):
+        check_close(p, rp, 2e-6, "resumed step with a new lr")
+    assert float(opt2.state[ps[0]]["step"]) == 4.0
+
+
+def test_adam_full_model_parameter_set_and_folded_momentum():
+    """All 470 single-tensor groups of S3D InfoNCE (235 with gradients): one launch, parity with
+    torch per tensor, and with fold_momentum the key encoder equals EXACTLY what the model's own
+    momentum update (model/pretrain.py:76-80) would have produced from the updated query weights."""
+    import model.pretrain as product
+    from coclr_amd import optim as O
+    torch.manual_seed(0)
+    model = product.InfoNCE('s3d', 128, 64, 0.999, 0.07).cuda()
+    named = list(model.named_parameters())
+    assert len(named) == 470
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    ref_params = {n: p.detach().cpu().clone().requires_grad_(p.requires_grad) for n, p in named}
+    ref = O._TorchAdam([{"params": p} for p in ref_params.values()], lr=1e-3, weight_decay=1e-5)
+    opt = O.Adam([{"params": p} for _, p in named], lr=1e-3, weight_decay=1e-5, fold_momentum=True)
+    k_before = [p.detach().clone() for p in model.encoder_k.parameters()]
+    for step in range(2):
+        for n, p in named:
+            if p.requires_grad:
+                p.grad = torch.randn(p.shape, device="cuda", generator=gen) * 0.01
+                ref_params[n].grad = p.grad.cpu()
+        opt.step()
+        ref.step()
+        assert opt._plan["n"] == 235 and opt._plan["fold"] is not None
+        worst = 0.0
+        for n, p in named:
+            if p.requires_grad:
+                e = float((p.detach().cpu() - ref_params[n].detach()).abs().max() /
+                          (ref_params[n].detach().abs().max() + 1e-12))
+                worst = max(worst, e)
+        assert worst <= 2e-6, worst
+        # folded momentum update: bit-identical to p_k*m + p_q_new*(1-m) in fp32
+        m = model.m
+        for pk, pq, kb in zip(model.encoder_k.parameters(), model.encoder_q.parameters(), k_before):
+            assert torch.equal(pk.detach(), kb * m + pq.detach() * (1. - m))
+        assert model.__dict__["_momentum_folded"] == float(m)
+        # the next training forward must skip its own update exactly once
+        assert model._momentum_pre(True) is None
+        assert model._momentum_pre(True) == model._momentum_update_key_encoder
+        k_before = [p.detach().clone() for p in model.encoder_k.parameters()]
+
+
+def test_training_steps_with_native_optimizer_and_loss_match_reference_sequence():
+    """Two whole training steps (InfoNCE small fixture) driven the way the launch scripts drive
+    them, but with the native optimiser + fused loss: same logits / queue as the reference run
+    recorded in tests/golden (which used nn.CrossEntropyLoss and torch.optim.Adam)."""
+    import model.pretrain as product
+    from coclr_amd import loss as L
+    from _cases import build_model, case_inputs, compare_step
+    gold = load_golden("infonce_s3d_small")
+    cfg = gold["cfg"]
+    model = build_model(cfg, product).cuda().train()
+    opt = torch.optim.Adam([{"params": p} for _, p in model.named_parameters()], lr=1e-3,
+                           weight_decay=1e-5)
+    assert type(opt).__module__ == "coclr_amd.optim"
+    crit = L.CrossEntropyLoss()
+    rec = gold["steps"][0]
+    blocks, _ = case_inputs(cfg, 0)
+    torch.manual_seed(cfg["perm_seed"])
+    out, tgt = model(blocks[0].cuda())
+    loss = crit(out, tgt)
+    top1, top5 = L.calc_topk_accuracy(out, tgt, (1, 5))
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert opt._plan is not None and opt._plan["n"] == 235
+    check_close(out, rec["logits"], 1e-3, "logits")
+    check_close(loss, rec["loss"], 1e-3, "loss")
+    assert 0.0 <= float(top1) <= float(top5) <= 1.0
+    for k, ref in rec["params_after"].items():
+        check_close(model.state_dict()[k], ref, 1e-3, "param after Adam " + k)
+
+
+# ---- loss + accuracy ----------------------------------------------------------------------------
+
+def _loss_cases():
+    for rec in load_golden("next_loss_epilogue")["cases"]:
+        yield rec
+    # the K=16384 queue of BASELINE configs 3 and 5, judged against the oracle on the host
+    g = torch.Generator().manual_seed(3)
+    B, K = 32, 16384
+    q = F.normalize(torch.randn(B, 128, generator=g), dim=1)
+    queue = F.normalize(torch.randn(128, K, generator=g), dim=0)
+    k = F.normalize(q + 0.7 * torch.randn(B, 128, generator=g), dim=1)
+    logits = torch.cat([(q * k).sum(1, keepdim=True), q @ queue], 1) / 0.07
+    mask = torch.rand(B, 1 + K, generator=g) < (4.0 / K)
+    mask[:, 0] = True
+    mask[3, 1:] = False
+    target = torch.zeros(B, dtype=torch.long)
+    rec = {"logits": logits, "mask": mask, "target": target}
+    for name, fn in (("ce", lambda lg: F.cross_entropy(lg, target)),
+                     ("multi", lambda lg: orc.multi_nce_loss(lg, mask)),
+                     ("multi_drop", lambda lg: orc.masked_nce_loss_drop_self(lg, mask)),
+                     ("uber", lambda lg: orc.ubernce_loss(lg, mask))):
+        lg = logits.clone().requires_grad_(True)
+        loss = fn(lg)
+        loss.backward()
+        rec[name] = {"loss": loss.detach(), "dlogits": lg.grad}
+    rec["topk_self"] = orc.calc_topk_accuracy(logits, target, (1, 5))
+    rec["topk_mask"] = orc.calc_mask_accuracy(logits, mask, (1, 5))
+    yield rec
+
+
+def test_loss_epilogue_matches_reference():
+    from coclr_amd import loss as L
+    for rec in _loss_cases():
+        logits, mask, target = rec["logits"].cuda(), rec["mask"].cuda(), rec["target"].cuda()
+        for name, fn in (("ce", lambda lg: L.CrossEntropyLoss()(lg, target)),
+                         ("multi", lambda lg: L.multi_nce_loss(lg, mask)),
+                         ("multi_drop", lambda lg: L.multi_nce_loss(lg, mask, drop_self=True)),
+                         ("uber", lambda lg: L.ubernce_loss(lg, mask))):
+            lg = logits.clone().requires_grad_(True)
+            loss = fn(lg)
+            (2.0 * loss).backward()                       # a non-unit upstream gradient
+            check_close(loss, rec[name]["loss"], 1e-6, name + " loss")
+            check_close(lg.grad, 2.0 * rec[name]["dlogits"], 1e-5, name + " dlogits")
+            if name == "ce":
+                got = L.calc_topk_accuracy(lg, target, (1, 5))
+                assert [float(v) for v in got] == [float(v) for v in rec["topk_self"]]
+            else:
+                got = L.calc_mask_accuracy(lg, mask, (1, 5)) + L.calc_self_accuracy(lg, (1, 5))
+                want = list(rec["topk_mask"]) + list(rec["topk_self"])
+                assert [float(v) for v in got] == [float(v) for v in want], name
+        # stand-alone accuracy calls (no loss ran on this tensor), single k
+        fresh = logits.clone()
+        assert float(L.calc_topk_accuracy(fresh, target, (1,))[0]) == float(rec["topk_self"][0])
+        assert float(L.calc_mask_accuracy(fresh, mask, (5,))[0]) == float(rec["topk_mask"][1])
+
+
+def test_loss_non_zero_targets_and_row_without_positive():
+    from coclr_amd import loss as L
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(9, 77, generator=g) * 3
+    target = torch.randint(0, 77, (9,), generator=g)
+    lg = logits.cuda().requires_grad_(True)
+    loss = L.cross_entropy(lg, target.cuda())
+    loss.backward()
+    ref = logits.clone().requires_grad_(True)
+    rl = F.cross_entropy(ref, target)
+    rl.backward()
+    check_close(loss, rl, 1e-6, "CE with arbitrary targets")
+    check_close(lg.grad, ref.grad, 1e-5, "CE dlogits")
+    got = L.calc_topk_accuracy(lg, target.cuda(), (1, 5))
+    want = orc.calc_topk_accuracy(logits, target, (1, 5))
+    assert [float(v) for v in got] == [float(v) for v in want]
+    mask = torch.zeros(9, 77, dtype=torch.bool)
+    mask[:, 0] = True
+    mask[2] = False                                        # no positive at all: loss = +inf, as the reference
+    out = L.multi_nce_loss(logits.cuda(), mask.cuda())
+    assert torch.isinf(out) and torch.isinf(orc.multi_nce_loss(logits, mask))
+
+
+# ---- input staging ----------------------------------------------------------------------------------
+
+def test_staging_bit_exact():
+    from coclr_amd import staging
+    g = load_golden("next_staging")
+    out = staging.tr(g["u8"].cuda(), g["num_seq"], g["seq_len"])
+    assert torch.equal(out.cpu(), g["out"])
+    out = staging.tr((g["u8"].float() / 255).cuda(), g["num_seq"], g["seq_len"])
+    assert torch.equal(out.cpu(), g["out"])
+    # benchmark clip shape (2 x 32 frames of 128x128), odd batch, both input types, host path
+    gen = torch.Generator().manual_seed(6)
+    u8 = torch.randint(0, 256, (3, 3, 64, 128, 128), generator=gen, dtype=torch.uint8)
+    want = orc.tr(u8, 2, 32)
+    assert torch.equal(staging.tr(u8.cuda(), 2, 32).cpu(), want)
+    assert torch.equal(staging.tr((u8.float() / 255).cuda(), 2, 32).cpu(), want)
+    stager = staging.ClipStager(2, 32)
+    for _ in range(3):                                     # pinned double buffering, reused
+        assert torch.equal(stager(u8).cpu(), want)
+    # ragged run length (not a multiple of 16): scalar tail path
+    u8 = torch.randint(0, 256, (2, 3, 6, 5, 7), generator=gen, dtype=torch.uint8)
+    assert torch.equal(staging.tr(u8.cuda(), 2, 3).cpu(), orc.tr(u8, 2, 3))
+    assert torch.equal(staging.tr((u8.float() / 255).cuda(), 2, 3).cpu(), orc.tr(u8, 2, 3))
+
+
+# ---- evaluation consumers ----------------------------------------------------------------------------
+
+def test_linear_classifier_matches_reference():
+    import model.classifier as product
+    from test_next_cpu import _classifier_block, _classifier_state
+    g = load_golden("next_classifier")
+    clf = _classifier_state(g, product).cuda()
+    block = _classifier_block(g).cuda()
+    clf.eval()
+    with torch.no_grad():
+        logit, feat = clf(block)
+    check_close(logit, g["logit_eval"], 1e-3, "eval logit")
+    check_close(feat, g["feat_eval"], 1e-3, "eval feat")
+    clf.train()
+    clf.final_fc[0].p = 0.0
+    logit, feat = clf(block)
+    check_close(feat, g["feat_train"], 1e-3, "train feat")
+    F.cross_entropy(logit, g["target"].cuda()).backward()
+    assert all(p.grad is not None for p in clf.parameters())
+    check_close(clf.final_bn.running_mean, g["final_bn.running_mean"], 1e-3, "running_mean")
+
+
+def test_classifier_head_kernels_well_conditioned():
+    """BatchNorm1d (train + eval, forward + backward), Linear and dropout scaling of the classifier
+    head on random features, against ATen on the CPU."""
+    from coclr_amd.model.classifier import FeatureBatchNorm1d, FeatureDropout, FeatureLinear
+    torch.manual_seed(0)
+    N, Cc, ncls = 37, 200, 11
+    x = torch.randn(N, Cc) * 2 + 0.5
+    bn_ref = torch.nn.BatchNorm1d(Cc)
+    bn_ref.weight.data = torch.rand(Cc) + 0.5
+    bn_ref.bias.data = torch.randn(Cc)
+    fc_ref = torch.nn.Linear(Cc, ncls)
+    bn, fc = FeatureBatchNorm1d(Cc), FeatureLinear(Cc, ncls)
+    bn.load_state_dict(bn_ref.state_dict())
+    fc.load_state_dict(fc_ref.state_dict())
+    bn, fc = bn.cuda(), fc.cuda()
+    dy = torch.randn(N, ncls)
+    for training in (True, False):
+        bn.train(training)
+        bn_ref.train(training)
+        xr = x.clone().requires_grad_(True)
+        yr = fc_ref(bn_ref(xr))
+        yr.backward(dy)
+        xg = x.cuda().requires_grad_(True)
+        yg = fc(bn(xg))
+        yg.backward(dy.cuda())
+        check_close(yg, yr, 2e-4, "bn1d+linear fwd (training=%s)" % training)
+        check_close(xg.grad, xr.grad, 5e-4, "dx")
+        check_close(bn.weight.grad, bn_ref.weight.grad, 5e-4, "dgamma")
+        check_close(fc.weight.grad, fc_ref.weight.grad, 5e-4, "dW")
+        check_close(bn.running_var, bn_ref.running_var, 1e-5, "running_var")
+        for m_ in (bn, fc, bn_ref, fc_ref):
+            m_.zero_grad()
+    drop = FeatureDropout(0.25).cuda().train()
+    xg = torch.ones(64, 128, device="cuda", requires_grad=True)
+    y = drop(xg)
+    vals = sorted(y.detach().unique().tolist())
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / 0.75) < 1e-6
+    y.sum().backward()
+    assert torch.equal(xg.grad, y.detach())
+    drop.eval()
+    assert drop(xg) is xg
+
+
+def test_nn_retrieval_matches_reference():
+    from coclr_amd.eval.retrieval import nn_retrieval
+    g = load_golden("next_retrieval")
+    acc, sim, topidx = nn_retrieval(g["test_feature"].cuda(), g["test_label"].cuda(),
+                                    g["train_feature"].cuda(), g["train_label"].cuda())
+    check_close(sim, g["sim"], 2e-4, "sim")
+    # the k nearest neighbours: compare through the similarity values (ties / 1e-7 reorderings
+    # of near-equal neighbours do not change them)
+    got = torch.gather(g["sim"], 1, topidx.cpu().long())
+    want = torch.topk(g["sim"], 50, dim=1).values
+    check_close(got, want, 1e-5, "top-50 similarities")
+    assert [round(float(a), 5) for a in acc] == [round(a, 5) for a in g["acc"]]
+    # a training set larger than the LDS row cache (global-memory path), exact against torch.topk
+    gen = torch.Generator().manual_seed(8)
+    ntr, nte = 41000, 6
+    sim_big = torch.randn(nte, ntr, generator=gen)
+    trl = torch.randint(0, 50, (ntr,), generator=gen)
+    tel = torch.randint(0, 50, (nte,), generator=gen)
+    from coclr_amd import ops
+    ks = torch.tensor([1, 5, 20], dtype=torch.int32).cuda()
+    hits = torch.empty(nte, 3, device="cuda")
+    top = torch.empty(nte, 20, dtype=torch.int32, device="cuda")
+    ops.retrieval_hits(sim_big.cuda(), trl.cuda(), tel.cuda(), ks, hits, top)
+    tv, ti = torch.topk(sim_big, 20, dim=1)
+    assert torch.equal(top.cpu().long(), ti)
+    for i, k in enumerate((1, 5, 20)):
+        assert torch.equal(hits[:, i].cpu(), (trl[ti[:, :k]] == tel[:, None]).any(1).float())
