@@ -9,18 +9,25 @@ One "step" = one iteration of the reference's train_one_epoch body (main_nce.py:
 on one synthetic batch already resident in HBM:
     logits, labels = DDP(InfoNCE('s3d'))(block)      q fwd, momentum update, shuffle-BN,
                                                      k fwd, logits, enqueue (+ collectives)
-    loss = CrossEntropyLoss(logits, labels); optimizer.zero_grad(); loss.backward();
-    optimizer.step()                                 Adam lr 1e-3 wd 1e-5
-Metric (BASELINE.json): clips/sec over the whole job = B * world / step time, B = 32
-clips of 3x32x128x128 per GPU, fp32.  Nothing is skipped inside the timed region.
-Caller-side work that is not on the hot path (accuracy meters and their .item() syncs,
-tqdm, TensorBoard) is left out and the optimiser is torch's fused Adam over one param
-group -- both are noted in `config`.
+    loss = criterion(logits, labels); top1, top5 = calc_topk_accuracy(logits, labels, (1,5))
+    optimizer.zero_grad(); loss.backward(); optimizer.step()
+with the optimiser built exactly as main_nce.py:190-200 builds it: Adam(lr 1e-3, wd 1e-5) over ONE
+PARAM GROUP PER TENSOR (470 groups).  Metric (BASELINE.json): clips/sec over the whole job =
+B * world / step time, B = 32 clips of 3x32x128x128 per GPU, fp32.  Nothing is skipped inside the
+timed region.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN for the field contract), including
-  roofline     -- the dominant kernel (conv implicit GEMM of Conv_2c.conv1, fp32 MFMA),
-                  timed live with HIP events on the launch stream inside the timed region
-  cpu_baseline -- the CPU oracle (port of the reference step) on this host's cores, N=1 only
+Legs (all in the one JSON line):
+  value                    the drop-in: `torch.optim.Adam` resolved to the single-launch subclass by the
+                           model.pretrain shim, loss + accuracy through coclr_amd.loss (device scalars)
+  value_caller_optimizer   the same step with torch's OWN Adam over the same 470 groups and
+                           nn.CrossEntropyLoss (what an unpatched caller would get)
+  roofline        dominant kernel (Conv_2c.conv1, spatial Winograd): MFMA FLOPs ACTUALLY ISSUED / time
+                  / 157.3 TF, in-step (HIP events on the launch stream) and isolated; the
+                  direct-convolution-equivalent figure is kept as `direct_equiv`
+  roofline_hbm    largest BatchNorm+ReLU apply launch (Conv_1a.bn1): algorithmic bytes / time / 8 TB/s
+  roofline_nce    the q.queue^T logits GEMM at K=16384: bytes and FLOPs / time, MFMA-busy from the
+                  PMC pass committed under profiles/
+  cpu_baseline    the CPU oracle (port of the reference step) on this host's cores, N=1 only
 """
 import argparse
 import json
@@ -52,6 +59,12 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=32)
     ap.add_argument("--img-dim", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip value_caller_optimizer and the isolated roofline micro-runs")
+    ap.add_argument("--dry-run-host", action="store_true",
+                    help="launch-contract rehearsal on the host (gloo, tiny shapes): only valid when "
+                         "the caller has replaced coclr_amd.ops by the tests' ATen double "
+                         "(tests/bench_dryrun.py); never a measurement")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="intra-op threads of the CPU baseline (16 is the fastest on the 128-core "
@@ -71,36 +84,35 @@ def synthetic_block(B, seq_len, img_dim, device, seed):
 
 
 class KernelTimer:
-    """HIP-event timing of selected conv launches on the stream they are enqueued on
-    (our kernels run on torch's current stream, so torch.cuda.Event brackets them)."""
+    """HIP-event timing of selected launches on the stream they are enqueued on (our kernels run
+    on torch's current stream, so torch.cuda.Event brackets them)."""
 
-    def __init__(self, match):
-        self.match = match
-        self.events = []
+    def __init__(self):
+        self.events = {}
         self.enabled = False
 
-    def install(self):
-        from coclr_amd import ops
-        inner = ops.conv_fwd
+    def wrap(self, module, name, key, match):
+        inner = getattr(module, name)
         timer = self
 
-        def timed_conv_fwd(geom, *a, **kw):
-            if timer.enabled and timer.match(geom):
+        def timed(*a, **kw):
+            if timer.enabled and match(*a, **kw):
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-                inner(geom, *a, **kw)
+                inner(*a, **kw)
                 e1.record()
-                timer.events.append((e0, e1))
+                timer.events.setdefault(key, []).append((e0, e1))
             else:
-                inner(geom, *a, **kw)
+                inner(*a, **kw)
 
-        ops.conv_fwd = timed_conv_fwd
+        setattr(module, name, timed)
 
-    def mean_ms(self):
-        if not self.events:
-            return None
-        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+    def mean_ms(self, key):
+        ev = self.events.get(key)
+        if not ev:
+            return None, 0
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)
 
 
 def cpu_baseline(args):
@@ -109,13 +121,14 @@ def cpu_baseline(args):
     import torch.nn.functional as F
     from oracle import coclr_oracle as orc
     from model.pretrain import InfoNCE
+    from coclr_amd.optim import _TorchAdam
     B, K = 4, 2048
     torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     torch.manual_seed(0)
     model = InfoNCE(args.net, 128, K, 0.999, 0.07)
     sd = orc.training_state(model.state_dict())
     leaves = [sd[k] for k, _ in model.named_parameters() if sd[k].requires_grad]
-    opt = torch.optim.Adam([{"params": p} for p in leaves], lr=1e-3, weight_decay=1e-5)
+    opt = _TorchAdam([{"params": p} for p in leaves], lr=1e-3, weight_decay=1e-5)
     times = []
     for step in range(1 + args.cpu_steps):
         g = torch.Generator().manual_seed(100 + step)
@@ -132,8 +145,48 @@ def cpu_baseline(args):
     dt = sum(times) / len(times)
     return {"value": round(B / dt, 3), "unit": "clips/sec", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": "%d timed steps (1 warm-up) of S3D InfoNCE K=2048 B=4 3x%dx%dx%d fwd+bwd+Adam, "
-                      "%.2f s/step" % (len(times), args.seq_len, args.img_dim, args.img_dim, dt)}
+            "sample": "%d timed steps (1 warm-up) of S3D InfoNCE K=2048 B=4 3x%dx%dx%d fwd+bwd+Adam "
+                      "through oracle/coclr_oracle.py (the reference's ATen CPU kernels) on %d of "
+                      "this host's %d hardware threads, %.2f s/step"
+                      % (len(times), args.seq_len, args.img_dim, args.img_dim,
+                         torch.get_num_threads(), os.cpu_count() or 0, dt)}
+
+
+def nce_roofline(device, B):
+    """The contrastive GEMM of BASELINE configs 3/5 (model/pretrain.py:175-182): q (B x 128) against
+    the K=16384 queue, alone on the chip.  Bytes: queue + q + k + logits; FLOPs: 2*B*128*K."""
+    import torch.nn.functional as F
+    from coclr_amd import ops
+    K, D, T = 16384, 128, 0.07
+    g = torch.Generator(device=device).manual_seed(5)
+    q = F.normalize(torch.randn(B, D, device=device, generator=g), dim=1)
+    k = F.normalize(torch.randn(B, D, device=device, generator=g), dim=1)
+    queue = F.normalize(torch.randn(D, K, device=device, generator=g), dim=0)
+    logits = torch.empty(B, 1 + K, device=device)
+    for _ in range(5):
+        ops.nce_logits_fwd(q, k, queue, logits, T)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 200
+    e0.record()
+    for _ in range(reps):
+        ops.nce_logits_fwd(q, k, queue, logits, T)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    flop = 2.0 * B * D * K
+    byts = 4.0 * (D * K + 2 * B * D + B * (1 + K))
+    rec = {"kernel": "nce_logits_fwd (l_pos + q.queue^T, /T) B=%d dim=128 K=16384, back-to-back "
+                     "launches alone on the chip (includes the launch boundary)" % B,
+           "avg_launch_us": round(us, 2), "bound": "hbm",
+           "achieved": round(byts / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4),
+           "algorithmic_mb_per_launch": round(byts / 1e6, 2),
+           "tflops": round(flop / us / 1e6, 2),
+           "mfma_frac_of_fp32_peak": round(flop / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    pj = os.path.join(ROOT, "profiles", "r02_nce_pmc.json")
+    if os.path.exists(pj):
+        rec["pmc"] = json.load(open(pj))
+    return rec
 
 
 def main():
@@ -146,13 +199,25 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    dry = args.dry_run_host
+    if dry:
+        from coclr_amd import ops as _ops
+        if _ops.conv_fwd.__module__ == "coclr_amd.ops":
+            raise SystemExit("--dry-run-host needs the tests' double (python tests/bench_dryrun.py)")
+        device = torch.device("cpu")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.synchronize = lambda *a, **k: None
+        args.no_extra_legs = args.no_cpu_baseline = True
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from coclr_amd import _lib
     _lib.load()                      # fail loudly if the HIP library is missing
-    from model.pretrain import InfoNCE, CoCLR
+    from model.pretrain import InfoNCE, CoCLR         # the shim also resolves torch.optim.Adam
+    from coclr_amd import loss as L, ops, engine
+    from coclr_amd.optim import Adam as NativeAdam, _TorchAdam
 
     K = args.moco_k or (2048 if world == 1 else 16384)
     B = args.batch
@@ -163,11 +228,17 @@ def main():
         model = CoCLR(args.net, 128, K, 0.999, 0.07, topk=5)
         model.queue_label.fill_(1)       # queue "full": cross-modal mining active
         model.queue_vname.copy_(torch.randint(0, 2 ** 31, (K,)))
-    model = model.cuda(local_rank)
-    ddp = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
-    params = [p for p in ddp.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-5, fused=True)
-    criterion = nn.CrossEntropyLoss().cuda(local_rank)
+        model.queue_is_full = True
+    if dry:
+        ddp = nn.parallel.DistributedDataParallel(model)
+    else:
+        model = model.cuda(local_rank)
+        ddp = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    # main_nce.py:190-200: one param group per tensor, frozen ones included
+    groups = [{"params": p} for _, p in ddp.named_parameters()]
+    opt = torch.optim.Adam(groups, lr=1e-3, weight_decay=1e-5)
+    assert isinstance(opt, NativeAdam), "the model.pretrain shim should have resolved torch.optim.Adam"
+    criterion = L.CrossEntropyLoss()
     ddp.train()
     if args.model == "coclr":
         model.sampler.eval()
@@ -177,53 +248,83 @@ def main():
              for j in range(nblk)] for i in range(2)]
     vsrc = torch.randint(0, 2 ** 31, (B,), device=device)
 
-    # dominant kernel: Conv_2c.conv1 = (1,3,3) 64->192 on (T/2, H/4, W/4), three launches per step
-    # (q forward, k forward, q data-gradient of the same geometry class is 192->64 and excluded)
+    # dominant kernel: Conv_2c.conv1 = (1,3,3) 64->192 on (T/2, H/4, W/4): the query encoder's forward
+    # launches (the key encoder's replay from a hipGraph and cannot be bracketed)
     tq, hq = args.seq_len // 2, args.img_dim // 4
-    def is_dominant(g):
-        return g.k == (1, 3, 3) and g.Cin == 64 and g.Cout == 192 and g.idim == (tq, hq, hq) \
-            and g.d == (1, 1, 1)
-    timer = KernelTimer(is_dominant)
-    timer.install()
+    th, hh = args.seq_len, args.img_dim // 2          # Conv_1a.bn1 output extent
+    timer = KernelTimer()
+    if not dry:
+        timer.wrap(ops, "conv_fwd", "dominant",
+                   lambda g, *a, **kw: g.k == (1, 3, 3) and g.Cin == 64 and g.Cout == 192
+                   and g.idim == (tq, hq, hq) and g.d == (1, 1, 1))
+        timer.wrap(ops, "bn_act_apply", "bn_apply",
+                   lambda y, *a, **kw: tuple(y.shape) == (B, 64, th, hh, hh))
 
-    def step(i):
+    acc = {}
+
+    def step(i, native=True):
         blocks = pool[i % 2]
         if args.model == "infonce":
             out, tgt = ddp(blocks[0])
-            loss = criterion(out, tgt)
+            if native:
+                loss = criterion(out, tgt)
+                acc["top1"], acc["top5"] = L.calc_topk_accuracy(out, tgt, (1, 5))
+            else:
+                loss = nn.functional.cross_entropy(out, tgt)
         else:
             out, mask = ddp(blocks[0], blocks[1], vsrc)
-            loss = (- torch.log((torch.softmax(out, dim=1) * mask).sum(1))).mean()
-        opt.zero_grad(set_to_none=True)
+            if native:
+                loss = L.multi_nce_loss(out, mask, drop_self=True)
+                acc["top1"], acc["top5"] = L.calc_mask_accuracy(out, mask, (1, 5))
+            else:
+                loss = (- torch.log((torch.softmax(out, dim=1) * mask).sum(1))).mean()
+        cur.zero_grad(set_to_none=True)
         loss.backward()
-        opt.step()
+        cur.step()
         return loss
 
+    def timed_run(nsteps, native):
+        dist.barrier()
+        torch.cuda.synchronize()
+        calls0 = _lib.CALLS[0]
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            loss = step(i, native)
+        t_host = time.perf_counter() - t0       # host enqueue time (no sync inside the loop)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax), t_host, (_lib.CALLS[0] - calls0) / nsteps, float(loss.detach())
+
+    cur = opt
     for i in range(args.warmup):
         step(i)
-    dist.barrier()
-    torch.cuda.synchronize()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    t_host = time.perf_counter() - t0       # host enqueue time (no sync inside the loop)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    timer.enabled = not dry
+    dt, t_host, calls_per_step, final_loss = timed_run(args.steps, True)
     timer.enabled = False
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
-    final_loss = float(loss.detach())
+    assert dry or opt._plan is not None, "the single-launch Adam did not run"
 
-    # the same dominant kernel alone on the chip (the in-step launches above share the CUs with the
-    # key-encoder / weight-gradient streams): 20 back-to-back launches of Conv_2c.conv1
-    iso_ms = None
-    iso_algo = 0
-    if rank == 0 and args.net == "s3d":
-        from coclr_amd import ops, engine
+    # ---- the same step as an unpatched caller gets it: torch's own Adam over the 470 groups ----------
+    caller = None
+    if not args.no_extra_legs:
+        cur = _TorchAdam(groups, lr=1e-3, weight_decay=1e-5)
+        for i in range(2):
+            step(i, native=False)
+        n2 = max(3, min(args.steps, 10))
+        dt2, t_host2, _, _ = timed_run(n2, False)
+        caller = {"value": round(B * world * n2 / dt2, 2), "ms_per_step": round(dt2 / n2 * 1e3, 3),
+                  "steps": n2, "host_enqueue_ms_per_step": round(t_host2 / n2 * 1e3, 2),
+                  "what": "torch.optim.Adam (torch's implementation) over %d single-tensor groups + "
+                          "nn.functional.cross_entropy, everything else identical" % len(groups)}
+        cur = opt
+
+    # ---- isolated micro-runs on rank 0: the dominant kernel, the largest BN apply, the NCE GEMM ------
+    iso_ms = bn_iso_ms = None
+    nce = None
+    if rank == 0 and args.net == "s3d" and not args.no_extra_legs:
         g = ops.conv_geom(B, 64, 192, (tq, hq, hq), (1, 3, 3), (1, 1, 1), (0, 1, 1))   # as the model
         run = engine.Run(device, save=False)
         xi = torch.randn(B, 64, tq, hq, hq, device=device)
@@ -231,8 +332,6 @@ def main():
         yi = torch.empty(B, 192, *g.odim, device=device)
         sti = torch.empty(2 * 192 * g.ntiles(), device=device)
         wpi = run.pack(wi, False, algo=g.algo)
-        iso_algo = g.algo
-        timer.enabled = False
         for _ in range(3):
             ops.conv_fwd(g, xi, wpi, yi, stats=sti)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -242,49 +341,74 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         iso_ms = e0.elapsed_time(e1) / 20
+        assert g.algo == 1
         del xi, wi, yi, sti
+        yb = torch.randn(B, 64, th, hh, hh, device=device)
+        zb = torch.empty_like(yb)
+        sc = torch.rand(2, 64, device=device) + 0.5
+        for _ in range(3):
+            ops.bn_act_apply(yb, sc[0], sc[1], None, zb, True)
+        e0.record()
+        for _ in range(20):
+            ops.bn_act_apply(yb, sc[0], sc[1], None, zb, True)
+        e1.record()
+        torch.cuda.synchronize()
+        bn_iso_ms = e0.elapsed_time(e1) / 20
+        del yb, zb
+        nce = nce_roofline(device, B)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         clips = B * world * args.steps / dt
-        kms = timer.mean_ms()
-        flops = 2.0 * B * 192 * 64 * 9 * tq * hq * hq          # algorithmic, per launch
-        wino = bool(iso_ms) and iso_algo == 1
-        kname = ("conv_wino_hw_kernel<8,6> Winograd F(2x2,3x3)" if wino
-                 else "conv_igemm_kernel<1,3,3,8,64,128,4>")
+        kms, nk = timer.mean_ms("dominant")
+        flops = 2.0 * B * 192 * 64 * 9 * tq * hq * hq          # direct-convolution FLOPs per launch
+        issued = flops * 16.0 / 36.0                             # F(2x2,3x3): 16 of 36 products
         roof = None
         traffic = None
-        tj = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath) and args.net == "s3d" and B == 32:
             # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
             # (counters cannot be read from inside the process)
             tj = json.load(open(tpath))
-            if wino != ("wino" in tj["kernel"]):
-                tj = None
-        if tj is not None:
-            traffic = {"bytes_per_launch": tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"],
-                       "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
-                       "source": tj["source"]}
+            if "wino" in tj["kernel"]:
+                traffic = {"bytes_per_launch": tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"],
+                           "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
+                           "source": tj["source"]}
         if kms:
-            ach = flops / (kms * 1e-3) / 1e12
+            ach = issued / (kms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic,
-                    "kernel": "%s (Conv_2c.conv1 64->192, %dx%dx%d, "
-                              "N=%d; the query encoder's launches inside the timed steps, which share "
-                              "the chip with the key-encoder stream)" % (kname, tq, hq, hq, B),
-                    "launches_timed": len(timer.events), "avg_launch_ms": round(kms, 4),
-                    "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
-            if wino:
-                # algorithmic = the direct convolution's FLOPs; the kernel issues 16/36 of them as MFMAs
-                roof["mfma_gflop_per_launch"] = round(flops * 16.0 / 36.0 / 1e9, 2)
-                roof["mfma_frac"] = round(ach * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS, 4)
+                    "kernel": "conv_wino_hw_kernel<8,6> Winograd F(2x2,3x3) (Conv_2c.conv1 64->192, "
+                              "%dx%dx%d, N=%d; the query encoder's forward launches inside the timed "
+                              "steps, sharing the chip with the key-encoder stream)" % (tq, hq, hq, B),
+                    "launches_timed": nk, "avg_launch_ms": round(kms, 4),
+                    "mfma_gflop_per_launch": round(issued / 1e9, 2),
+                    "what": "achieved = MFMA FLOPs the kernel actually issues (16 of the 36 products "
+                            "of the direct convolution) / average launch time",
+                    "direct_equiv": {"algorithmic_gflop_per_launch": round(flops / 1e9, 2),
+                                     "achieved": round(flops / (kms * 1e-3) / 1e12, 2),
+                                     "frac": round(flops / (kms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}}
             if iso_ms:
-                # same kernel, same geometry, nothing else running: the kernel's own efficiency
                 roof["isolated"] = {"avg_launch_ms": round(iso_ms, 4),
-                                    "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
-                                    "frac": round(flops / (iso_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                                    "achieved": round(issued / (iso_ms * 1e-3) / 1e12, 2),
+                                    "frac": round(issued / (iso_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                    "direct_equiv_frac": round(flops / (iso_ms * 1e-3) / 1e12 /
+                                                               FP32_MFMA_PEAK_TFLOPS, 4)}
+        bms, nb = timer.mean_ms("bn_apply")
+        roof_hbm = None
+        if bms:
+            byts = 2.0 * 4 * B * 64 * th * hh * hh            # read y, write z
+            roof_hbm = {"bound": "hbm", "kernel": "bn_act_apply_kernel<relu> on Conv_1a.bn1 "
+                                                  "(%dx64x%dx%dx%d): z = relu(y*scale+shift)" % (B, th, hh, hh),
+                        "achieved": round(byts / (bms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(byts / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "algorithmic_mb_per_launch": round(byts / 1e6, 1), "launches_timed": nb,
+                        "avg_launch_ms": round(bms, 4)}
+            if bn_iso_ms:
+                roof_hbm["isolated"] = {"avg_launch_ms": round(bn_iso_ms, 4),
+                                        "achieved": round(byts / (bn_iso_ms * 1e-3) / 1e9, 1),
+                                        "frac": round(byts / (bn_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         # whole-step view against both rooflines (91.46 GF, 2145 MB per clip)
         step_view = {"tflops_per_gpu": round(91.46e9 * B / (ms * 1e-3) / 1e12, 2),
                      "frac_fp32_peak": round(91.46e9 * B / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -296,16 +420,26 @@ def main():
                 {"infonce": "InfoNCE", "coclr": "CoCLR"}[args.model], args.seq_len, B),
             "value": round(clips, 2), "unit": "clips/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
+            "data": "synthetic" if not dry else "DRY RUN ON THE HOST (ATen double, not a measurement)",
             "config": {"workload": "%s %s moco-k=%d seq_len=%d img=%d bs=%d/GPU, DDP(nccl=RCCL) x%d, "
-                                   "fwd+CE+bwd+Adam(fused, lr 1e-3, wd 1e-5)"
-                                   % (args.net, args.model, K, args.seq_len, args.img_dim, B, world),
+                                   "fwd + loss + top-1/5 + bwd + Adam(lr 1e-3, wd 1e-5) over %d "
+                                   "single-tensor param groups (main_nce.py:190-200)"
+                                   % (args.net, args.model, K, args.seq_len, args.img_dim, B, world,
+                                      len(groups)),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "excluded_caller_work": "accuracy meters/.item() syncs, dataloader+H2D",
+                       "optimizer": "coclr_amd.optim.Adam (torch.optim.Adam resolved by the "
+                                    "model.pretrain shim): one launch per step",
+                       "loss": "coclr_amd.loss (loss + top-1/top-5 in one pass, device scalars)",
+                       "excluded_caller_work": "meters' .item() syncs, dataloader + H2D",
                        "final_loss": round(final_loss, 4)},
-            "roofline": roof, "step_roofline": step_view,
+            "roofline": roof, "roofline_hbm": roof_hbm, "roofline_nce": nce,
+            "step_roofline": step_view,
             "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 2),
+            "abi_calls_per_step": round(calls_per_step, 1),
         }
+        if caller is not None:
+            rec["value_caller_optimizer"] = caller
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)
     dist.barrier()

@@ -116,9 +116,13 @@ def load():
     return lib
 
 
+CALLS = [0]      # C-ABI calls made so far (bench.py reports calls per step)
+
+
 def check(rc, what, detail=None):
     """`detail` (e.g. a geometry object) is only formatted when the call failed: these wrappers
     run ~1500 times per training step."""
+    CALLS[0] += 1
     if rc != 0:
         if detail is not None:
             what = "%s %s" % (what, detail)

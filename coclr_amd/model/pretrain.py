@@ -17,6 +17,7 @@ Differences are all below the API:
 """
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.distributed as dist
@@ -39,31 +40,25 @@ def _world():
 
 def route_plan(perm, B, world, rank):
     """Routing of the shuffle-BN exchange for one rank.  `perm` is the global permutation
-    (list of B*world clip ids, clip g lives on rank g // B at local index g % B); rank r encodes
+    (B*world clip ids, clip g lives on rank g // B at local index g % B); rank r encodes
     the clips perm[r*B:(r+1)*B] in that order.  Returns
       send_order  local indices of this rank's clips laid out by destination rank (for each
                   destination, in the order that destination wants them),
       in_splits   clips sent to each rank,  out_splits  clips received from each rank,
       pos         pos[i] = row of the receive buffer (rows grouped by source rank, all_to_all
-                  order) that holds the i-th clip this rank has to encode."""
-    send_order, in_splits = [], []
-    for r in range(world):
-        mine = [g % B for g in perm[r * B:(r + 1) * B] if g // B == rank]
-        send_order += mine
-        in_splits.append(len(mine))
-    wanted = perm[rank * B:(rank + 1) * B]
-    out_splits = [sum(1 for g in wanted if g // B == src) for src in range(world)]
-    offs, acc = [], 0
-    for c in out_splits:
-        offs.append(acc)
-        acc += c
-    seen = [0] * world
-    pos = []
-    for g in wanted:
-        src = g // B
-        pos.append(offs[src] + seen[src])
-        seen[src] += 1
-    return send_order, in_splits, out_splits, pos
+                  order) that holds the i-th clip this rank has to encode.
+    Vectorised (numpy): this runs on the host in front of every training forward."""
+    perm = np.asarray(perm, dtype=np.int64)
+    src = perm // B                                   # owner of the clip encoded at position i
+    mine = np.nonzero(src == rank)[0]                 # positions whose clip lives here, ascending
+    send_order = perm[mine] % B                       # = grouped by destination (i // B), then by i
+    in_splits = np.bincount(mine // B, minlength=world)
+    wsrc = src[rank * B:(rank + 1) * B]
+    out_splits = np.bincount(wsrc, minlength=world)
+    order = np.argsort(wsrc, kind="stable")           # receive buffer: by source, arrival order kept
+    pos = np.empty(B, dtype=np.int64)
+    pos[order] = np.arange(B)
+    return send_order.tolist(), in_splits.tolist(), out_splits.tolist(), pos.tolist()
 
 
 @torch.no_grad()
@@ -335,6 +330,9 @@ class InfoNCE(nn.Module):
             flat = self.__dict__["_flat_buffers"]
         world, _ = _world()
         if world > 1:
+            # new_group is a collective: every rank creates the host-side channel HERE, at its first
+            # forward, whatever shuffle scheme / train-or-eval path it takes afterwards
+            self._host_group()
             with torch.no_grad():
                 dist.broadcast(flat, src=0)
 
@@ -563,21 +561,48 @@ class InfoNCE(nn.Module):
         host, so each rank sends a clip only to the rank that will encode it: B clips leave and
         B clips arrive per rank, whatever the world size.
         Returns (recv buffer (B, C, T, H, W), n_index: row of the buffer holding the i-th clip
-        of this rank's shuffled mini-batch, idx_unshuffle)."""
+        of this rank's shuffled mini-batch, idx_unshuffle).
+        Host side: numpy routing, ONE pinned staging buffer and ONE host-to-device copy for the
+        three index vectors (send order, receive positions, un-shuffle)."""
         world, rank = _world()
         B = x2.shape[0]
-        perm = torch.randperm(B * world)                  # same RNG use as the reference (:112)
+        BW = B * world
+        perm = torch.randperm(BW)                         # same RNG use as the reference (:112)
         dist.broadcast(perm, src=0, group=self._host_group())
-        send_order, in_splits, out_splits, pos = route_plan(perm.tolist(), B, world, rank)
+        pn = perm.numpy()
+        src = pn // B
+        mine = np.nonzero(src == rank)[0]
+        wsrc = src[rank * B:(rank + 1) * B]
+        in_splits = np.bincount(mine // B, minlength=world).tolist()
+        out_splits = np.bincount(wsrc, minlength=world).tolist()
         dev = x2.device
-        order_t = torch.tensor(send_order, dtype=torch.int64).to(dev, non_blocking=True)
+        st = self.__dict__.get("_route_staging")
+        if st is None or st[0].shape[0] != 2 * B + BW or st[1].device != dev:
+            host = torch.empty(2 * B + BW, dtype=torch.int64)
+            if dev.type == "cuda":
+                host = host.pin_memory()
+            st = self.__dict__["_route_staging"] = [host, torch.empty(2 * B + BW, dtype=torch.int64,
+                                                                      device=dev), None]
+        host, devbuf, ev = st
+        if ev is not None:
+            ev.synchronize()                              # last step's copy has read the buffer
+        h = host.numpy()
+        h[:B] = pn[mine] % B                              # send order: by destination, then position
+        h[B:2 * B][np.argsort(wsrc, kind="stable")] = np.arange(B)   # receive positions
+        h[2 * B:] = np.argsort(pn, kind="stable")         # un-shuffle (a permutation: any sort)
+        devbuf.copy_(host, non_blocking=True)
+        if dev.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            st[2] = ev
+        order_t, n_index, idx_unshuffle = devbuf[:B], devbuf[B:2 * B], devbuf[2 * B:]
         sendbuf = torch.empty((B,) + tuple(x2.shape[1:]), dtype=x2.dtype, device=dev)
         ops.gather_rows(x2, order_t, sendbuf)
         recvbuf = torch.empty_like(sendbuf)
         dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=out_splits,
                                input_split_sizes=in_splits)
-        n_index = torch.tensor(pos, dtype=torch.int64).to(dev, non_blocking=True)
-        idx_unshuffle = torch.argsort(perm).to(dev, non_blocking=True)
+        # the index vectors are views of a buffer the next step overwrites: the key path consumes
+        # them (shuffle gather, un-shuffle) before this forward returns, on this stream
         return recvbuf, n_index, idx_unshuffle
 
     @torch.no_grad()

@@ -354,3 +354,127 @@ def test_resumed_queue_pointer_is_validated(fake):
     m.load_state_dict(sd)
     m(torch.randn(4, 2, 3, 8, 32, 32))
     assert int(m.queue_ptr) == 0
+
+
+def _multi_rank_worker(rank, world, kind, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        class MP:
+            @staticmethod
+            def setattr(obj, name, val):
+                setattr(obj, name, val)
+        fake_backend.install(MP)
+        import coclr_amd.model.pretrain as impl
+        import model.pretrain as product
+        B, K, clip = 2, 64, (3, 8, 32, 32)
+        assert K % (B * world) == 0
+
+        def run(routed):
+            impl._ROUTED_SHUFFLE = routed
+            torch.manual_seed(0)
+            if kind == "infonce":
+                model = product.InfoNCE('s3d', 128, K, 0.999, 0.07)
+            else:
+                model = product.CoCLR('s3d', 128, K, 0.999, 0.07, topk=5)
+                g = torch.Generator().manual_seed(7)
+                model.queue_label.fill_(1)
+                model.queue_vname.copy_(torch.randint(0, 6, (K,), generator=g))
+            ddp = torch.nn.parallel.DistributedDataParallel(model)
+            opt = torch.optim.Adam([{"params": p} for _, p in ddp.named_parameters()], lr=1e-3,
+                                   weight_decay=1e-5)
+            ddp.train()
+            if kind == "coclr":
+                model.sampler.eval()
+            outs = []
+            for step in range(2):
+                g = torch.Generator().manual_seed(50 + step)
+                blocks = [torch.randn(B * world, 2, *clip, generator=g) for _ in range(2)]
+                vsrc = torch.randint(0, 6, (B * world,), generator=g)
+                sl = slice(rank * B, (rank + 1) * B)
+                torch.manual_seed(900 + step)              # same permutation on every rank / scheme
+                if kind == "infonce":
+                    out, tgt = ddp(blocks[0][sl])
+                    loss = torch.nn.functional.cross_entropy(out, tgt)
+                else:
+                    out, mask = ddp(blocks[0][sl], blocks[1][sl], vsrc[sl])
+                    loss = (- torch.log((torch.softmax(out, dim=1) * mask).sum(1))).mean()
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                outs.append(out.detach().clone())
+            sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            return outs, sd
+
+        outs_r, sd_r = run(True)
+        outs_a, sd_a = run(False)
+        # the routed all-to-all delivers exactly the clips the reference's all-gather + index keeps
+        for a, b in zip(outs_r, outs_a):
+            assert torch.equal(a, b), "routed vs all-gather logits differ"
+        for k in sd_r:
+            assert torch.equal(sd_r[k], sd_a[k]), "routed vs all-gather state differs: " + k
+        # replicas stay bit-identical: queues (all of them), pointer, BN buffers after the broadcast
+        for k in [k for k in sd_r if k.startswith("queue")] + ["encoder_q.4.bias"]:
+            t = sd_r[k].double().reshape(-1)
+            digest = torch.stack([t.sum(), (t * torch.arange(1, t.numel() + 1, dtype=torch.float64)).sum()])
+            got = [torch.zeros_like(digest) for _ in range(world)]
+            dist.all_gather(got, digest)
+            assert all(torch.equal(got[0], d) for d in got), "replicas diverged in " + k
+        assert int(sd_r["queue_ptr"]) == (2 * B * world) % K
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+@pytest.mark.parametrize("world,kind,port", [(4, "infonce", 29711), (8, "infonce", 29712),
+                                             (4, "coclr", 29713), (8, "coclr", 29714)])
+def test_four_and_eight_rank_gloo(world, kind, port):
+    """world_size 4 and 8 over gloo (kernels replaced by the ATen double): two DDP training steps of
+    InfoNCE / CoCLR with the routed shuffle-BN exchange and with the reference's all-gather scheme
+    -- bit-identical logits and state between the two, queues / pointer / parameters bit-identical
+    across ranks.  The only multi-rank evidence available without an 8-GPU node."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_multi_rank_worker, args=(r, world, kind, port, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_bench_launch_contract_dry_run(world):
+    """bench.py launched exactly as the driver launches it (torch.distributed.run, one process per
+    rank), on the host with the ATen double: one JSON line from rank 0 with the contract's fields,
+    whole-job value = B*world*steps/time, K = 16384 and weak scaling at world > 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29720 + world),
+           os.path.join(root, "tests", "bench_dryrun.py"), "--gpus", str(world), "--steps", "2",
+           "--warmup", "1"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in rec, key
+    assert rec["n_gpus"] == world and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["scaling"] == "weak" and rec["higher_is_better"] is True and rec["dtype"] == "fp32"
+    assert rec["config"]["global_batch"] == 2 * world and "DRY RUN" in rec["data"]
+    assert ("moco-k=16384" in rec["config"]["workload"]) == (world > 1)
+    assert abs(rec["value"] - 2 * world * 2 / (rec["ms_per_step"] * 2e-3)) <= 0.02 * rec["value"]
