@@ -153,6 +153,106 @@ lpos_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, float*
   if (lane == 0) logits[row * ldl] = s * inv_T;
 }
 
+// ---------------------------------------------------------------------------
+// logits[b][0] = <q_b, k_b>/T,  logits[b][1+j] = <q_b, queue[:, j]>/T     (model/pretrain.py:175-182)
+//
+// The contraction the north star names: M = batch (<= 32 rows per tile), N = K queue columns,
+// reduction over D = 128.  12.8 FLOP per byte of queue -> HBM / latency bound: ONE launch, one
+// workgroup per 64 queue columns (256 workgroups at K = 16384, one per CU), no split-K workspace.
+//   * q (16 KB) goes through LDS once per workgroup (coalesced 16-byte loads);
+//   * the queue tile is read straight into MFMA operand registers: lane (k-half, n) of
+//     v_mfma_f32_32x32x2_f32 takes queue[d][n0+n], so a half-wave reads 128 contiguous bytes of a
+//     queue row -- no LDS round trip, no barrier on the streaming operand;
+//   * the four waves split D (32 channels each), meet through 32 KB of LDS and store the
+//     [32][64] tile scaled by 1/T; workgroup 0 also emits the positive column.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256)
+nce_logits_kernel(const float* __restrict__ q, const float* __restrict__ kpos,
+                  const float* __restrict__ queue, float* __restrict__ logits, int B, int K,
+                  float inv_T) {
+  constexpr int NT = 64, DW = D / 4, STEPS = DW / 2, LDQ = D + 1;
+  __shared__ float qs[32 * LDQ];
+  __shared__ float part[4][32][NT + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int n0 = blockIdx.x * NT, m0 = blockIdx.y * 32;
+
+  // this wave's slice of the queue tile goes straight to MFMA operand registers; every global
+  // load of the workgroup (queue slice, positive keys, q) is issued before anything waits
+  const int d0 = wave * DW;
+  float bv[2][STEPS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = n0 + t * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+      bv[t][s] = col < K ? queue[(long)(d0 + 2 * s + half) * K + col] : 0.f;
+  }
+  float kv[8][D / 64];
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int j = 0; j < D / 64; ++j)
+        kv[r][j] = m0 + wave * 8 + r < B ? kpos[(long)(m0 + wave * 8 + r) * D + lane + 64 * j] : 0.f;
+  }
+  // q tile -> LDS (rows past B are zero)
+  {
+    float4 qv[32 * D / 4 / 256];
+#pragma unroll
+    for (int i = 0; i < 32 * D / 4 / 256; ++i) {
+      const int e = tid + i * 256;
+      const int r = e / (D / 4), c4 = e - r * (D / 4);
+      qv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + r < B) qv[i] = reinterpret_cast<const float4*>(q + (long)(m0 + r) * D)[c4];
+    }
+#pragma unroll
+    for (int i = 0; i < 32 * D / 4 / 256; ++i) {
+      const int e = tid + i * 256;
+      const int r = e / (D / 4), c4 = e - r * (D / 4);
+      float* d = &qs[r * LDQ + c4 * 4];
+      d[0] = qv[i].x; d[1] = qv[i].y; d[2] = qv[i].z; d[3] = qv[i].w;
+    }
+  }
+  __syncthreads();
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const float av = qs[l31 * LDQ + d0 + 2 * s + half];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[0][s], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[1][s], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = (i & 3) + 8 * (i >> 2) + 4 * half;
+    part[wave][r][l31] = acc0[i];
+    part[wave][r][32 + l31] = acc1[i];
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * NT; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    if (m0 + r < B && n0 + c < K) {
+      const float v = (part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c]);
+      logits[(long)(m0 + r) * (1 + K) + 1 + n0 + c] = v * inv_T;
+    }
+  }
+  if (blockIdx.x == 0) {
+    // positive column: wave w owns rows 8w..8w+7, keys already in registers
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = wave * 8 + r;
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < D / 64; ++j) sacc += qs[row * LDQ + lane + 64 * j] * kv[r][j];
+      sacc = wave_sum(sacc);
+      if (lane == 0 && m0 + row < B) logits[(long)(m0 + row) * (1 + K)] = sacc * inv_T;
+    }
+  }
+}
+
 // dq[b][:] += dlogits[b][0] * inv_T * k[b][:]
 __global__ void lpos_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ k,
                                 float* dq, int rows, int D, long ldl, float inv_T) {
@@ -352,6 +452,13 @@ extern "C" int coclr_nce_logits_fwd(const float* q, const float* k, const float*
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || D <= 0 || K <= 0 || T == 0.f) return COCLR_EINVAL;
   const float inv_T = 1.f / T;
+  if (D == 128 && ((uintptr_t)q & 15) == 0) {
+    // the head's own shape (dim = 128, model/pretrain.py:32): one fused launch
+    hipLaunchKernelGGL((nce_logits_kernel<128>), dim3(cdiv(K, 64), cdiv(B, 32)), dim3(256), 0, stream,
+                       q, k, queue, logits, B, K, inv_T);
+    COCLR_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(lpos_fwd_kernel, dim3(cdiv((long)B * 64, 256)), dim3(256), 0, stream, q, k,
                      logits, B, D, (long)(1 + K), inv_T);
   COCLR_LAUNCH_CHECK();
