@@ -18,7 +18,23 @@ struct PoolGeom {
   int Ti, Hi, Wi, To, Ho, Wo;
   int kt, kh, kw, st, sh, sw, pt, ph, pw;
   long x_nstride, y_nstride;   // floats between samples (channel slices allowed)
+  // optional transform of the INPUT, applied as it is read: x' = x*in_scale[c] + in_shift[c], then
+  // max(x', 0) when in_relu -- the BatchNorm+ReLU that precedes the pool (backbone/s3dg.py:60-64
+  // then :151,162; the block outputs before :173,190), so the normalised tensor is never written
+  const float* in_scale;
+  const float* in_shift;
+  int in_relu;
+  int C0;                      // channels before T was folded into the plane count
+  int tfold;
 };
+
+__device__ __forceinline__ float pool_in(const PoolGeom& g, float v, int c) {
+  if (g.in_scale) {
+    v = fmaf(v, g.in_scale[c], g.in_shift[c]);
+    if (g.in_relu) v = fmaxf(v, 0.f);
+  }
+  return v;
+}
 
 __global__ void __launch_bounds__(256)
 maxpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ idx,
@@ -43,7 +59,7 @@ maxpool3d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int* __
         for (int h = h0; h < h1; ++h)
           for (int w = w0; w < w1; ++w) {
             const int ii = (t * g.Hi + h) * g.Wi + w;
-            const float v = xp[ii];
+            const float v = pool_in(g, xp[ii], c);
             if (v > best || v != v) { best = v; bi = ii; }
           }
       yp[o] = best;
@@ -110,11 +126,16 @@ maxpool3d_tiled_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
     const int n = pl / g.C, c = pl - n * g.C;
     const float* xp = x + (long)n * g.x_nstride + (long)c * Si;
     float* tp = tile + gi * Si;
+    const int ch = c / g.tfold;          // channel of the un-folded tensor
     if ((Si & 3) == 0 && ((g.x_nstride & 3) == 0)) {
-      for (int i = threadIdx.x; i < (Si >> 2); i += 256)
-        reinterpret_cast<float4*>(tp)[i] = reinterpret_cast<const float4*>(xp)[i];
+      for (int i = threadIdx.x; i < (Si >> 2); i += 256) {
+        float4 v = reinterpret_cast<const float4*>(xp)[i];
+        v.x = pool_in(g, v.x, ch); v.y = pool_in(g, v.y, ch);
+        v.z = pool_in(g, v.z, ch); v.w = pool_in(g, v.w, ch);
+        reinterpret_cast<float4*>(tp)[i] = v;
+      }
     } else {
-      for (int i = threadIdx.x; i < Si; i += 256) tp[i] = xp[i];
+      for (int i = threadIdx.x; i < Si; i += 256) tp[i] = pool_in(g, xp[i], ch);
     }
   }
   __syncthreads();
@@ -224,6 +245,108 @@ maxpool3d_tiled_bwd_kernel(const float* __restrict__ dy, const int* __restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// 3x3x3 / stride 1 / pad 1 (the pool branch of every inception block, backbone/s3dg.py:105) on
+// small planes (H*W = 256, 64 or 16).  The 27-element scan with argmax tracking is VALU-bound
+// (~110 operations per output); the maximum is separable, and so is "first maximum in (t, h, w)
+// scan order": max over w, then over h, then over t, each stage keeping the earliest of equal
+// values -- 6 combines per output instead of 26.  Thread = (volume, h, w); it walks t with a
+// three-plane sliding window of in-plane maxima.  NaN handling and the initial argmax (first
+// in-range element) are those of the scan above.
+// ---------------------------------------------------------------------------
+struct PoolBest { float v; int i; };
+
+__device__ __forceinline__ void pool_take(PoolBest& b, float cv, int ci) {
+  if (cv > b.v || cv != cv) { b.v = cv; b.i = ci; }
+}
+
+template <bool WITH_IDX, int TT>
+__global__ void __launch_bounds__(256)
+maxpool333_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ idx,
+                  const PoolGeom g, int planes, int lW, int lHW) {
+  extern __shared__ float lds[];
+  const int T = TT > 0 ? TT : g.Ti;                  // compile-time frame count: the t loops unroll
+  const int W = 1 << lW, HW = 1 << lHW, H = HW >> lW;
+  const int PG = 256 >> lHW, S = T << lHW;          // volumes per workgroup, floats per volume
+  float* xs = lds;                                   // [PG][T][HW]
+  float* bv = xs + PG * S;                           // w-stage maxima
+  int* bi = reinterpret_cast<int*>(bv + PG * S);     // ... and their flat indices
+  const int tid = threadIdx.x;
+  const int pl0 = blockIdx.x * PG;
+  const int gcount = min(PG, planes - pl0);
+  for (int gi = 0; gi < gcount; ++gi) {
+    const int pl = pl0 + gi;
+    const int n = pl / g.C, c = pl - n * g.C;
+    const float* xp = x + (long)n * g.x_nstride + (long)c * S;
+    float* tp = xs + gi * S;
+    if ((g.x_nstride & 3) == 0) {
+      for (int i = tid; i < (S >> 2); i += 256) {
+        float4 v = reinterpret_cast<const float4*>(xp)[i];
+        v.x = pool_in(g, v.x, c); v.y = pool_in(g, v.y, c);
+        v.z = pool_in(g, v.z, c); v.w = pool_in(g, v.w, c);
+        reinterpret_cast<float4*>(tp)[i] = v;
+      }
+    } else {
+      for (int i = tid; i < S; i += 256) tp[i] = pool_in(g, xp[i], c);
+    }
+  }
+  __syncthreads();
+  const int gl = tid >> lHW, p = tid & (HW - 1), h = p >> lW, w = p & (W - 1);
+  const bool live = gl < gcount;
+  // stage 1: along w
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int row = (gl * T + t) * HW + h * W;
+      const int frow = (t * H + h) * W;              // flat index of the row start in the volume
+      PoolBest b;
+      b.v = -INFINITY;
+      b.i = frow + (w > 0 ? w - 1 : 0);
+      if (w > 0) pool_take(b, xs[row + w - 1], frow + w - 1);
+      pool_take(b, xs[row + w], frow + w);
+      if (w < W - 1) pool_take(b, xs[row + w + 1], frow + w + 1);
+      bv[row + w] = b.v;
+      if (WITH_IDX) bi[row + w] = b.i;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  // stage 2 (along h) for one plane
+  auto plane_best = [&](int t) {
+    const int col = (gl * T + t) * HW + w;
+    const int h0 = h > 0 ? h - 1 : 0;
+    PoolBest b;
+    b.v = -INFINITY;
+    b.i = WITH_IDX ? bi[col + h0 * W] : 0;
+    if (h > 0) pool_take(b, bv[col + (h - 1) * W], WITH_IDX ? bi[col + (h - 1) * W] : 0);
+    pool_take(b, bv[col + h * W], WITH_IDX ? bi[col + h * W] : 0);
+    if (h < H - 1) pool_take(b, bv[col + (h + 1) * W], WITH_IDX ? bi[col + (h + 1) * W] : 0);
+    return b;
+  };
+  const int pl = pl0 + gl;
+  const int n = pl / g.C, c = pl - n * g.C;
+  float* yp = y + (long)n * g.y_nstride + (long)c * S;
+  int* ip = WITH_IDX ? idx + (long)pl * S : nullptr;
+  // stage 3: sliding window along t
+  PoolBest prev, cur = plane_best(0), next = cur;
+  prev.v = -INFINITY; prev.i = cur.i;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) next = plane_best(t + 1);
+    PoolBest b;
+    b.v = -INFINITY;
+    b.i = t > 0 ? prev.i : cur.i;                  // first in-range element of the window
+    if (t > 0) pool_take(b, prev.v, prev.i);
+    pool_take(b, cur.v, cur.i);
+    if (t + 1 < T) pool_take(b, next.v, next.i);
+    yp[t * HW + p] = b.v;
+    if (WITH_IDX) ip[t * HW + p] = b.i;
+    prev = cur;
+    cur = next;
+  }
+}
+
 constexpr int kTileFloats = 16384;   // 64 KiB of LDS per workgroup
 
 // planes per workgroup so that the tile is <= kTileFloats and there are enough workgroups
@@ -244,13 +367,13 @@ int launch_tiled_fwd(const PoolGeom& g, const float* x, float* y, int* idx, int 
   const int blocks = (planes + G - 1) / G;
   if (idx) {
     auto k = maxpool3d_tiled_fwd_kernel<KT, KH, KW, ST, SH, SW, WPT, true>;
-    static bool done = false;
-    if (!done) { COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kTileFloats * 4)); done = true; }
+    static std::atomic<uint64_t> done{0};
+    COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(k), kTileFloats * 4, done));
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, stream, x, y, idx, g, G, planes, tfold);
   } else {
     auto k = maxpool3d_tiled_fwd_kernel<KT, KH, KW, ST, SH, SW, WPT, false>;
-    static bool done = false;
-    if (!done) { COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kTileFloats * 4)); done = true; }
+    static std::atomic<uint64_t> done{0};
+    COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(k), kTileFloats * 4, done));
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, stream, x, y, idx, g, G, planes, tfold);
   }
   COCLR_LAUNCH_CHECK();
@@ -263,6 +386,7 @@ inline PoolGeom fold_time(PoolGeom g) {
     // (n, c, t) volumes of H*W: only valid when samples are dense in (C,T,H,W), which
     // holds for channel-slice views as long as C*T planes of one sample are contiguous
     g.C = g.C * g.Ti;
+    g.tfold = g.Ti;
     g.Ti = g.To = 1;
   }
   return g;
@@ -303,16 +427,52 @@ inline PoolGeom to_geom(const coclr_pool_desc* d) {
   g.kt = d->kt; g.kh = d->kh; g.kw = d->kw; g.st = d->st; g.sh = d->sh; g.sw = d->sw;
   g.pt = d->pt; g.ph = d->ph; g.pw = d->pw;
   g.x_nstride = d->x_nstride; g.y_nstride = d->y_nstride;
+  g.in_scale = g.in_shift = nullptr; g.in_relu = 0; g.C0 = d->C; g.tfold = 1;
   return g;
 }
 
 }  // namespace
 
+static inline int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (1 << l) == v ? l : -1;
+}
+
 extern "C" int coclr_maxpool3d_fwd(const coclr_pool_desc* d, const float* x, float* y,
-                                   int32_t* indices, void* stream) {
+                                   int32_t* indices, const float* in_scale, const float* in_shift,
+                                   int in_relu, void* stream) {
   if (!d || d->N <= 0 || d->C <= 0) return COCLR_EINVAL;
   if (d->pt * 2 > d->kt || d->ph * 2 > d->kh || d->pw * 2 > d->kw) return COCLR_EINVAL;
-  const PoolGeom g = to_geom(d);
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return COCLR_EINVAL;
+  PoolGeom g = to_geom(d);
+  g.in_scale = in_scale; g.in_shift = in_shift; g.in_relu = in_relu;
+  if (g.kt == 3 && g.kh == 3 && g.kw == 3 && g.st == 1 && g.sh == 1 && g.sw == 1 && g.pt == 1 &&
+      g.ph == 1 && g.pw == 1) {
+    // inception pool branch: separable scan, thread = (volume, h, w)
+    const int lW = ilog2_exact(g.Wi), lHW = ilog2_exact(g.Hi * g.Wi);
+    if (lW >= 0 && lHW >= 4 && lHW <= 8 && g.Ti <= 32) {
+      const int PG = 256 >> lHW, S = g.Ti << lHW;
+      const int planes = g.N * g.C;
+      const size_t lds = (size_t)PG * S * 4 * (indices ? 3 : 2);
+      if (lds <= 64 * 1024) {
+        const dim3 grid(cdiv(planes, PG));
+        hipStream_t st = (hipStream_t)stream;
+#define POOL333(TT)                                                                                  \
+        if (indices) hipLaunchKernelGGL((maxpool333_kernel<true, TT>), grid, dim3(256), lds, st, x, y, \
+                                        indices, g, planes, lW, lHW);                                \
+        else hipLaunchKernelGGL((maxpool333_kernel<false, TT>), grid, dim3(256), lds, st, x, y,       \
+                                indices, g, planes, lW, lHW)
+        if (g.Ti == 16) { POOL333(16); }
+        else if (g.Ti == 8) { POOL333(8); }
+        else if (g.Ti == 4) { POOL333(4); }
+        else { POOL333(0); }
+#undef POOL333
+        COCLR_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+  }
   {
     // LDS-tiled fast paths; T is folded into the plane count when the stencil ignores it
     const PoolGeom f = fold_time(g);
@@ -349,12 +509,9 @@ extern "C" int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, co
     const int planes = g.N * g.C;
     const int G = pick_group(planes, Si);
     if (G > 0) {
-      static bool done = false;
-      if (!done) {
-        COCLR_RETURN_IF(hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool3d_tiled_bwd_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kTileFloats * 4));
-        done = true;
-      }
+      static std::atomic<uint64_t> done{0};
+      COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(maxpool3d_tiled_bwd_kernel),
+                                     kTileFloats * 4, done));
       hipLaunchKernelGGL(maxpool3d_tiled_bwd_kernel, dim3((planes + G - 1) / G), dim3(256),
                          (size_t)G * Si * sizeof(float), (hipStream_t)stream, dy, indices, dx, g,
                          (long)dy_nstride, (long)dx_nstride, accumulate, G, planes, tfold);

@@ -131,20 +131,34 @@ def _plan_for(module, save, device):
 
 
 class Val:
-    """An activation: channels [c0, c0+C) of the dense NCDHW tensor `base`."""
-    __slots__ = ("base", "c0", "C")
+    """An activation: channels [c0, c0+C) of the dense NCDHW tensor `base`.
+
+    `lazy` = (y, scale, shift, relu): the activation is relu(y*scale + shift) of a BatchNorm unit
+    whose apply pass has NOT run yet.  A consumer that can apply the affine itself while reading
+    (the max-pool kernels) takes `lazy` and the tensor is never written; anybody else calls
+    `view()`, which runs the apply pass into `base` first."""
+    __slots__ = ("base", "c0", "C", "lazy")
 
     def __init__(self, base, c0=0, C=None):
         self.base = base
         self.c0 = c0
         self.C = base.shape[1] - c0 if C is None else C
+        self.lazy = None
 
     @property
     def whole(self):
         return self.c0 == 0 and self.C == self.base.shape[1]
 
     def view(self):
-        return self.base if self.whole else self.base[:, self.c0:self.c0 + self.C]
+        v = self.base if self.whole else self.base[:, self.c0:self.c0 + self.C]
+        if self.lazy is not None:
+            if self.lazy == "consumed":
+                raise RuntimeError("coclr_amd: activation was consumed in fused form (its tensor "
+                                   "was never written) and cannot be read again")
+            y, scale, shift, relu = self.lazy
+            self.lazy = None
+            ops.bn_act_apply(y, scale, shift, None, v, relu)
+        return v
 
     @property
     def shape(self):
@@ -442,9 +456,10 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
 
     small = run.empty(4, Cout)       # mean, invstd, scale, shift
     mean, invstd, scale, shift = small[0], small[1], small[2], small[3]
+    lazy_ok = out is None         # a private output tensor: nobody else writes or reads it yet
     if out is None:
         out = Val(run.empty(N, Cout, *odim))
-    zv = out.view()
+    zv = out.base if out.whole else out.view()
     y = None
     if want_y:
         y = run.empty(N, Cout, *odim)
@@ -465,8 +480,11 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
         else:
             ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
                                Cout, mean, invstd, scale, shift)
-        ops.bn_act_apply(y, scale, shift, residual.view() if residual is not None else None, zv,
-                         relu)
+        if LAZY_APPLY and residual is None and lazy_ok:
+            out.lazy = (y, scale, shift, relu)       # applied by the consumer (see Val)
+        else:
+            ops.bn_act_apply(y, scale, shift, residual.view() if residual is not None else None, zv,
+                             relu)
     else:
         # inference with frozen statistics: fold BN+ReLU into the conv epilogue
         ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
@@ -526,6 +544,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
     return out
 
 
+LAZY_APPLY = os.environ.get("COCLR_LAZY_APPLY", "1") != "0"
 FUSE_POINTWISE = True     # debugging switch: False runs the units of a group one by one
 
 
@@ -623,7 +642,14 @@ def max_pool(run, x, kernel, stride, padding):
     y = run.empty(N, Cc, *g.odim)
     need = run.needs_grad(x)
     idx = run.empty(N, Cc, *g.odim, dtype=torch.int32) if need else None
-    ops.maxpool_fwd(g, x.view(), y, idx)
+    if x.lazy is not None and x.whole:
+        # BatchNorm + ReLU of the producing unit applied while the pool reads its raw output: the
+        # normalised tensor is never written (its backward recomputes the ReLU mask from y)
+        ysrc, scale, shift, relu = x.lazy
+        x.lazy = "consumed"
+        ops.maxpool_fwd(g, ysrc, y, idx, in_scale=scale, in_shift=shift, in_relu=relu)
+    else:
+        ops.maxpool_fwd(g, x.view(), y, idx)
     out = Val(y)
     if need:
         def backward(run):

@@ -347,12 +347,14 @@ def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dga
 
 # ---- pooling ---------------------------------------------------------------------
 
-def maxpool_fwd(geom, x, y, indices=None):
+def maxpool_fwd(geom, x, y, indices=None, in_scale=None, in_shift=None, in_relu=False):
+    """in_scale / in_shift: per-channel affine (+ ReLU) applied to x as it is read -- the pool then
+    consumes the RAW convolution output of the BatchNorm unit in front of it."""
     d = geom.desc
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(y, "y")
-    _lib.check(_L().coclr_maxpool3d_fwd(C.byref(d), _p(x), _p(y),
-                                               _p(indices, torch.int32), _stream()),
+    _lib.check(_L().coclr_maxpool3d_fwd(C.byref(d), _p(x), _p(y), _p(indices, torch.int32),
+                                        _p(in_scale), _p(in_shift), int(in_relu), _stream()),
                "maxpool3d_fwd")
 
 

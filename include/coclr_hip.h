@@ -172,9 +172,12 @@ typedef struct coclr_pool_desc {
 } coclr_pool_desc;
 
 /* aten::max_pool3d_with_indices (floor mode, -inf padding, first max wins);
- * indices (optional, [N][C][To*Ho*Wo] int32) = flat offset inside the input plane. */
+ * indices (optional, [N][C][To*Ho*Wo] int32) = flat offset inside the input plane.
+ * in_scale / in_shift (optional, [C]): the input is read as x*in_scale[c] + in_shift[c], clamped at 0
+ * when in_relu -- the BatchNorm3d + ReLU in front of the pool (backbone/s3dg.py:60-64 before
+ * :151,:162) applied on the fly, so that the normalised activation is never written to HBM. */
 int coclr_maxpool3d_fwd(const coclr_pool_desc* d, const float* x, float* y, int32_t* indices,
-                        void* stream);
+                        const float* in_scale, const float* in_shift, int in_relu, void* stream);
 /* aten::max_pool3d_with_indices_backward, gather form (deterministic). */
 int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, const int32_t* indices, float* dx,
                         int64_t dy_nstride, int64_t dx_nstride, int accumulate, void* stream);

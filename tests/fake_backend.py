@@ -206,7 +206,11 @@ def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dga
         dy.copy_(_b(scale) * g)
 
 
-def maxpool_fwd(geom, x, y, indices=None):
+def maxpool_fwd(geom, x, y, indices=None, in_scale=None, in_shift=None, in_relu=False):
+    if in_scale is not None:
+        x = x * _b(in_scale) + _b(in_shift)
+        if in_relu:
+            x = torch.relu(x)
     out, idx = F.max_pool3d(x, geom.k, geom.s, geom.p, return_indices=True)
     y.copy_(out)
     if indices is not None:

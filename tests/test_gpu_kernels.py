@@ -269,7 +269,13 @@ POOLS = [((1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 5, 4, 16, 16)),
          ((3, 3, 3), (2, 2, 2), (1, 1, 1), (2, 6, 8, 8, 8)),
          ((2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 7, 4, 4, 4)),
          ((3, 3, 3), (1, 1, 1), (1, 1, 1), (3, 4, 4, 6, 5)),
-         ((1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 3, 2, 7, 7))]
+         ((1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 3, 2, 7, 7)),
+         # inception pool branch on power-of-two planes: the separable kernel (thread = (volume, h, w))
+         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 5, 16, 16, 16)),
+         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (3, 7, 8, 8, 8)),
+         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 37, 4, 4, 4)),
+         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 3, 1, 4, 4)),
+         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 3, 5, 8, 4))]
 
 
 @pytest.mark.parametrize("k,s,p,shape", POOLS)
@@ -292,6 +298,49 @@ def test_maxpool_fwd_bwd(k, s, p, shape):
     close(dx, x.grad + 0.5, what="maxpool bwd accumulate")
     ops.maxpool_bwd(g, dev(dy), idx, dx, accumulate=False)
     close(dx, x.grad, what="maxpool bwd")
+    # without indices (no-grad encoders), into a channel slice of a wider buffer
+    wide = torch.zeros(shape[0], shape[1] + 3, *g.odim, device="cuda")
+    ops.maxpool_fwd(g, dev(x.detach()), wide[:, 2:2 + shape[1]])
+    assert torch.equal(wide[:, 2:2 + shape[1]].cpu(), ref.detach())
+    assert float(wide[:, :2].abs().max()) == 0 and float(wide[:, 2 + shape[1]:].abs().max()) == 0
+    # values with -inf / NaN: ATen's scan semantics (NaN wins, all -inf keeps the first element)
+    xs = torch.randn(*shape)
+    xs.view(-1)[::7] = -float("inf")
+    xs.view(-1)[5::131] = float("nan")
+    if xs[0, 0].numel() >= 8:
+        xs[0, 0].fill_(-float("inf"))
+    ref2, ridx2 = F.max_pool3d(xs, k, s, p, return_indices=True)
+    ops.maxpool_fwd(g, dev(xs), y, idx)
+    assert torch.equal(torch.nan_to_num(y.cpu(), nan=123.0), torch.nan_to_num(ref2, nan=123.0))
+    assert torch.equal(idx.cpu().long(), ridx2)
+
+
+@pytest.mark.parametrize("k,s,p,shape", POOLS[:3] + POOLS[5:7])
+def test_maxpool_with_fused_batchnorm_relu_input(k, s, p, shape):
+    """max_pool(relu(y*scale + shift)) with the affine + ReLU applied while the pool reads y (the
+    BatchNorm unit in front of MaxPool_2a / MaxPool_3a, backbone/s3dg.py:151,162): identical to the
+    two-pass form, negative scales included."""
+    from coclr_amd import ops
+    torch.manual_seed(7)
+    yraw = torch.randn(*shape)
+    scale = torch.randn(shape[1])                    # both signs
+    shift = torch.randn(shape[1]) * 0.3
+    z = torch.relu(yraw * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
+    zd = torch.empty(shape, device="cuda")
+    ops.bn_act_apply(dev(yraw), dev(scale), dev(shift), None, zd, True)
+    g = ops.PoolGeom(shape[0], shape[1], shape[2:], k, s, p)
+    y2 = torch.empty(shape[0], shape[1], *g.odim, device="cuda")
+    i2 = torch.empty(shape[0], shape[1], *g.odim, dtype=torch.int32, device="cuda")
+    ops.maxpool_fwd(g, zd, y2, i2)                               # two passes
+    y1 = torch.empty_like(y2)
+    i1 = torch.empty_like(i2)
+    ops.maxpool_fwd(g, dev(yraw), y1, i1, in_scale=dev(scale), in_shift=dev(shift), in_relu=True)
+    assert torch.equal(y1, y2) and torch.equal(i1, i2)
+    ref, _ = F.max_pool3d(z, k, s, p, return_indices=True)
+    close(y1, ref, rtol=1e-6, what="fused bn+relu+pool")
+    ops.maxpool_fwd(g, dev(yraw), y1, None, in_scale=dev(scale), in_shift=dev(shift), in_relu=False)
+    ref2 = F.max_pool3d(yraw * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1), k, s, p)
+    close(y1, ref2, rtol=1e-6, what="fused affine+pool")
 
 
 def test_global_avgpool():

@@ -19,4 +19,6 @@ print("kernel time total per step: %.2f ms" % (tot/5/1e6/ (8/5)))   # 3 warmup +
 for r in rows[:28]:
     print("%8.3f ms/step %6d calls  %s" % (float(r["TotalDurationNs"])/8/1e6, int(r["Calls"]), r["Name"][:110]))
 PY
+t=$(find $OUT -name '*kernel_trace.csv' | head -1)
+python $GRAFT_REPO_ROOT/tools/trace_timeline.py $t > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_timeline.txt 2>&1
 find $OUT -name '*kernel_trace.csv' -size +20M -delete

@@ -6,7 +6,7 @@ ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Stream_Id"]),
        re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])) for r in rows]
 ev.sort()
 # step boundaries: the fused Adam kernels end a step
-ends = [e for s, e, st, n in ev if "FusedAdam" in n]
+ends = [e for s, e, st, n in ev if "FusedAdam" in n or "adam_multi_kernel" in n]
 # group consecutive adam launches (7 per step)
 bounds = []
 for t in ends:
