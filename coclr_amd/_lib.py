@@ -43,6 +43,8 @@ _SIGNATURES = {
     "coclr_conv3d_wgrad_workspace": [_P(ConvDesc), _P(i64)],
     "coclr_conv3d_wgrad": [_P(ConvDesc), vp, vp, vp, vp, i64, i64, i32, i32, vp],
     "coclr_bn_finalize": [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp],
+    "coclr_bn_finalize_apply": [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
+                                vp, vp, i32, i64, i64, i64, i32, vp],
     "coclr_bn_eval_affine": [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp],
     "coclr_bn_act_apply": [vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i64, i32, vp],
     "coclr_bn_backward_workspace": [i32, i32, _P(i64)],

@@ -259,6 +259,157 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
   }
 }
 
+// ---- small layers: one launch per BatchNorm unit ---------------------------------------------
+// In the last two stages of S3D a channel holds N*S = 2048..16384 values (4x4x4 / 8x8x8 maps): the
+// two-kernel forms above are launch-bound there (profiles/r01_e_layers.txt: 0.5-3.6 TB/s).  One
+// workgroup per channel does everything for its channel in one launch.
+
+// forward: fold the conv's partial sums, coefficients + running statistics, then z = act(y*sc+sf)
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_fwd_fused_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int ntiles,
+                    double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, float* mean_out, float* invstd_out, float* scale_out,
+                    float* shift_out, const float* __restrict__ y, float* z, int N, int S,
+                    long y_nstride, long z_nstride, int relu) {
+  __shared__ double red[4];
+  __shared__ float coef[2];
+  const int c = blockIdx.x;
+  const float* ps = sum + (long)c * ntiles;
+  const float* pq = sumsq + (long)c * ntiles;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < ntiles; i += 256) { s += (double)ps[i]; q += (double)pq[i]; }
+  s = block256_sum_d(s, red);
+  q = block256_sum_d(q, red);
+  if (threadIdx.x == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd, sf = b - (float)mean * sc;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    scale_out[c] = sc;
+    shift_out[c] = sf;
+    coef[0] = sc; coef[1] = sf;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  }
+  __syncthreads();
+  const float sc = coef[0], sf = coef[1];
+  if (VEC) {
+    const int S4 = S >> 2, total = N * S4;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int n = e / S4, i = e - n * S4;
+      float4 v = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
+      v.x = fmaf(v.x, sc, sf); v.y = fmaf(v.y, sc, sf); v.z = fmaf(v.z, sc, sf); v.w = fmaf(v.w, sc, sf);
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      reinterpret_cast<float4*>(z + (long)n * z_nstride + (long)c * S)[i] = v;
+    }
+  } else {
+    const int total = N * S;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int n = e / S, i = e - n * S;
+      float v = fmaf(y[(long)n * y_nstride + (long)c * S + i], sc, sf);
+      if (relu) v = fmaxf(v, 0.f);
+      z[(long)n * z_nstride + (long)c * S + i] = v;
+    }
+  }
+}
+
+// backward: sums of g and g*xhat over the channel, then dy = A*g + B*y + D (training) / scale*g
+// (eval); the second read of dz / y comes out of L2 (<= 128 KB per workgroup).
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_bwd_fused_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                    const float* __restrict__ scale, const float* __restrict__ shift,
+                    const float* __restrict__ mean, const float* __restrict__ invstd, int training,
+                    float* dgamma, float* dbeta, float* dy, int N, int S, long dz_nstride,
+                    long y_nstride, long dy_nstride, int relu) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  const float sc = scale[c], sf = shift[c], mu = mean[c], is = invstd[c];
+  double sg = 0.0, sgx = 0.0;
+  if (VEC) {
+    const int S4 = S >> 2, total = N * S4;
+    float ag = 0.f, agx = 0.f;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int n = e / S4, i = e - n * S4;
+      const float4 d = reinterpret_cast<const float4*>(dz + (long)n * dz_nstride + (long)c * S)[i];
+      const float4 v = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
+      float g0 = d.x, g1 = d.y, g2 = d.z, g3 = d.w;
+      if (relu) {
+        g0 = fmaf(v.x, sc, sf) > 0.f ? g0 : 0.f; g1 = fmaf(v.y, sc, sf) > 0.f ? g1 : 0.f;
+        g2 = fmaf(v.z, sc, sf) > 0.f ? g2 : 0.f; g3 = fmaf(v.w, sc, sf) > 0.f ? g3 : 0.f;
+      }
+      ag += (g0 + g1) + (g2 + g3);
+      agx += g0 * ((v.x - mu) * is) + g1 * ((v.y - mu) * is) + g2 * ((v.z - mu) * is) +
+             g3 * ((v.w - mu) * is);
+      if ((e & 0xfff) == 0xfff) { sg += (double)ag; sgx += (double)agx; ag = agx = 0.f; }
+    }
+    sg += (double)ag; sgx += (double)agx;
+  } else {
+    const int total = N * S;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int n = e / S, i = e - n * S;
+      float g = dz[(long)n * dz_nstride + (long)c * S + i];
+      const float v = y[(long)n * y_nstride + (long)c * S + i];
+      if (relu) g = fmaf(v, sc, sf) > 0.f ? g : 0.f;
+      sg += (double)g;
+      sgx += (double)(g * ((v - mu) * is));
+    }
+  }
+  sg = block256_sum_d(sg, red);
+  sgx = block256_sum_d(sgx, red);
+  float A = sc, B = 0.f, D = 0.f;
+  if (training) {
+    const double count = (double)N * (double)S;
+    const float mg = (float)(sg / count), mgx = (float)(sgx / count);
+    B = -sc * is * mgx;
+    D = sc * (mu * is * mgx - mg);
+  }
+  if (threadIdx.x == 0) {
+    if (dgamma) dgamma[c] = (float)sgx;
+    if (dbeta) dbeta[c] = (float)sg;
+  }
+  if (VEC) {
+    const int S4 = S >> 2, total = N * S4;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int n = e / S4, i = e - n * S4;
+      const float4 d = reinterpret_cast<const float4*>(dz + (long)n * dz_nstride + (long)c * S)[i];
+      const float4 v = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
+      float4 g = d;
+      if (relu) {
+        g.x = fmaf(v.x, sc, sf) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, sc, sf) > 0.f ? g.y : 0.f;
+        g.z = fmaf(v.z, sc, sf) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, sc, sf) > 0.f ? g.w : 0.f;
+      }
+      float4 o;
+      o.x = fmaf(A, g.x, fmaf(B, v.x, D)); o.y = fmaf(A, g.y, fmaf(B, v.y, D));
+      o.z = fmaf(A, g.z, fmaf(B, v.z, D)); o.w = fmaf(A, g.w, fmaf(B, v.w, D));
+      reinterpret_cast<float4*>(dy + (long)n * dy_nstride + (long)c * S)[i] = o;
+    }
+  } else {
+    const int total = N * S;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int n = e / S, i = e - n * S;
+      float g = dz[(long)n * dz_nstride + (long)c * S + i];
+      const float v = y[(long)n * y_nstride + (long)c * S + i];
+      if (relu) g = fmaf(v, sc, sf) > 0.f ? g : 0.f;
+      dy[(long)n * dy_nstride + (long)c * S + i] = fmaf(A, g, fmaf(B, v, D));
+    }
+  }
+}
+
+constexpr long kSmallChannel = 32768;     // N*S per channel up to which one workgroup per channel wins
+
 // Grid for the streaming kernels: x = chunks of one plane, y = (sample groups) x C.
 // Every block should see >= ~4096 elements: big planes get one block (or several) per
 // (n, c) plane, the 64..512-element planes of the last stages several samples per block.
@@ -296,6 +447,38 @@ extern "C" int coclr_bn_finalize(const float* sum, const float* sumsq, int C, in
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, sum, sumsq, C,
                      ntiles, count, gamma, beta, running_mean, running_var, num_batches_tracked,
                      momentum, eps, mean, invstd, scale, shift);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_bn_finalize_apply(const float* sum, const float* sumsq, int C, int ntiles,
+                                       double count, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, float momentum, float eps,
+                                       float* mean, float* invstd, float* scale, float* shift,
+                                       const float* y, float* z, int N, int64_t S, int64_t y_nstride,
+                                       int64_t z_nstride, int relu, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (C <= 0 || ntiles <= 0 || N <= 0 || S <= 0 || !y || !z) return COCLR_EINVAL;
+  if ((long)N * S > kSmallChannel) {
+    // large layers: statistics in one launch, the streaming apply pass in another
+    int rc = coclr_bn_finalize(sum, sumsq, C, ntiles, count, gamma, beta, running_mean, running_var,
+                               num_batches_tracked, momentum, eps, mean, invstd, scale, shift, stream_);
+    if (rc) return rc;
+    return coclr_bn_act_apply(y, scale, shift, nullptr, z, N, C, S, y_nstride, z_nstride, 0, relu,
+                              stream_);
+  }
+  const bool vec = (S % 4 == 0) && (y_nstride % 4 == 0) && (z_nstride % 4 == 0);
+  if (vec)
+    hipLaunchKernelGGL(bn_fwd_fused_kernel<true>, dim3(C), dim3(256), 0, stream, sum, sumsq, ntiles,
+                       count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                       eps, mean, invstd, scale, shift, y, z, N, (int)S, (long)y_nstride,
+                       (long)z_nstride, relu);
+  else
+    hipLaunchKernelGGL(bn_fwd_fused_kernel<false>, dim3(C), dim3(256), 0, stream, sum, sumsq, ntiles,
+                       count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                       eps, mean, invstd, scale, shift, y, z, N, (int)S, (long)y_nstride,
+                       (long)z_nstride, relu);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
@@ -348,6 +531,19 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
   const bool vec = (S % 4 == 0) && (dz_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
                    (dy_nstride % 4 == 0) && (!z || z_nstride % 4 == 0) &&
                    (!dres || dres_nstride % 4 == 0);
+  if (!z && !dres && (long)N * S <= kSmallChannel) {
+    // small layers: one workgroup per channel, one launch (the workspace is not used)
+    if (vec)
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<true>, dim3(C), dim3(256), 0, stream, dz, y, scale, shift,
+                         mean, invstd, training, dgamma, dbeta, dy, N, (int)S, (long)dz_nstride,
+                         (long)y_nstride, (long)dy_nstride, relu);
+    else
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<false>, dim3(C), dim3(256), 0, stream, dz, y, scale,
+                         shift, mean, invstd, training, dgamma, dbeta, dy, N, (int)S,
+                         (long)dz_nstride, (long)y_nstride, (long)dy_nstride, relu);
+    COCLR_LAUNCH_CHECK();
+    return 0;
+  }
   // pass 1: per (channel, sample group) partial sums of g and g*xhat
   const int groups = reduce_groups(N, (int)S);
   dim3 rgrid(C, groups);

@@ -470,19 +470,27 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                 stats = run.empty(2 * Cout * g.ntiles())
             ops.conv_fwd(g, xv, run.pack(w, False, t if sliced else None, algo=g.algo), y,
                          stats=stats if last else None, n_index=n_index, accumulate=t > 0)
+        count = N * odim[0] * odim[1] * odim[2]
+        lazy = LAZY_APPLY and residual is None and lazy_ok and count > ops.SMALL_CHANNEL
         if training:
             if bn.momentum is None:
                 raise NotImplementedError("coclr_amd: cumulative-average BatchNorm momentum")
-            ops.bn_finalize(stats, Cout, geoms[-1].ntiles(), N * odim[0] * odim[1] * odim[2],
-                            bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, float(bn.momentum), float(bn.eps), mean,
-                            invstd, scale, shift)
+            if residual is None and not lazy:
+                # statistics + apply in one call (a single launch for the small late-stage layers)
+                ops.bn_finalize_apply(stats, Cout, geoms[-1].ntiles(), count, bn.weight, bn.bias,
+                                      bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                      float(bn.momentum), float(bn.eps), mean, invstd, scale, shift,
+                                      y, zv, relu)
+            else:
+                ops.bn_finalize(stats, Cout, geoms[-1].ntiles(), count, bn.weight, bn.bias,
+                                bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                float(bn.momentum), float(bn.eps), mean, invstd, scale, shift)
         else:
             ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
                                Cout, mean, invstd, scale, shift)
-        if LAZY_APPLY and residual is None and lazy_ok:
+        if lazy:
             out.lazy = (y, scale, shift, relu)       # applied by the consumer (see Val)
-        else:
+        elif not (training and residual is None):
             ops.bn_act_apply(y, scale, shift, residual.view() if residual is not None else None, zv,
                              relu)
     else:
@@ -585,15 +593,18 @@ def pointwise_group(run, x, units):
         if training:
             if bn.momentum is None:
                 raise NotImplementedError("coclr_amd: cumulative-average BatchNorm momentum")
-            ops.bn_finalize(stats, C_, ntiles, count, bn.weight, bn.bias, bn.running_mean,
-                            bn.running_var, bn.num_batches_tracked, float(bn.momentum),
-                            float(bn.eps), mean, invstd, scale, shift, c0=c0, c_total=Ccat)
+            if out is None:
+                out = Val(run.empty(N, C_, *idim))
+            ops.bn_finalize_apply(stats, C_, ntiles, count, bn.weight, bn.bias, bn.running_mean,
+                                  bn.running_var, bn.num_batches_tracked, float(bn.momentum),
+                                  float(bn.eps), mean, invstd, scale, shift, y[:, c0:c0 + C_],
+                                  out.view(), True, c0=c0, c_total=Ccat)
         else:
             ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
                                C_, mean, invstd, scale, shift)
-        if out is None:
-            out = Val(run.empty(N, C_, *idim))
-        ops.bn_act_apply(y[:, c0:c0 + C_], scale, shift, None, out.view(), True)
+            if out is None:
+                out = Val(run.empty(N, C_, *idim))
+            ops.bn_act_apply(y[:, c0:c0 + C_], scale, shift, None, out.view(), True)
         outs.append(out)
         saved.append((c0, C_, mean, invstd, scale, shift))
         c0 += C_

@@ -311,6 +311,23 @@ def bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var
         _p(mean), _p(invstd), _p(scale), _p(shift), _stream()), "bn_finalize")
 
 
+def bn_finalize_apply(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt,
+                      momentum, eps, mean, invstd, scale, shift, y, z, relu, c0=0, c_total=None):
+    """bn_finalize + bn_act_apply (no residual) in one call; a single launch for small layers.
+    y: the [N][C_][S] channel range (a view) the statistics belong to."""
+    c_total = C_ if c_total is None else c_total
+    base = _p(stats)
+    N, _, T, H, W = y.shape
+    _lib.check(_L().coclr_bn_finalize_apply(
+        base + 4 * c0 * ntiles, base + 4 * (c_total + c0) * ntiles, C_, ntiles, float(count),
+        _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(nbt, torch.int64), momentum, eps,
+        _p(mean), _p(invstd), _p(scale), _p(shift), _p(y), _p(z), N, T * H * W, _chk5(y, "y"),
+        _chk5(z, "z"), int(relu), _stream()), "bn_finalize_apply")
+
+
+SMALL_CHANNEL = 32768      # N*S per channel up to which the one-launch BatchNorm forms are used
+
+
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps, C_, mean, invstd, scale, shift):
     _lib.check(_L().coclr_bn_eval_affine(
         _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, C_, _p(mean), _p(invstd),

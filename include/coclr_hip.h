@@ -135,6 +135,16 @@ int coclr_bn_finalize(const float* sum, const float* sumsq, int C, int ntiles, d
                       float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
 
+/* coclr_bn_finalize followed by coclr_bn_act_apply (no residual) as ONE call: for layers whose
+ * channels hold few values (N*S <= 32768: the 8x8x8 and 4x4x4 maps of S3D's last two stages) both
+ * run in a single launch, one workgroup per channel; larger layers take the two launches. */
+int coclr_bn_finalize_apply(const float* sum, const float* sumsq, int C, int ntiles, double count,
+                            const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, int64_t* num_batches_tracked, float momentum,
+                            float eps, float* mean, float* invstd, float* scale, float* shift,
+                            const float* y, float* z, int N, int64_t S, int64_t y_nstride,
+                            int64_t z_nstride, int relu, void* stream);
+
 /* Eval-mode coefficients from the running statistics (main_coclr.py:363). */
 int coclr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C, float* mean, float* invstd,

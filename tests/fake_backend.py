@@ -170,6 +170,16 @@ def _b(v):
     return v.view(1, -1, 1, 1, 1)
 
 
+def bn_finalize_apply(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt,
+                      momentum, eps, mean, invstd, scale, shift, y, z, relu, c0=0, c_total=None):
+    bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                mean, invstd, scale, shift, c0=c0, c_total=c_total)
+    bn_act_apply(y, scale, shift, None, z, relu)
+
+
+SMALL_CHANNEL = 32768
+
+
 def bn_act_apply(y, scale, shift, residual, z, relu):
     v = y * _b(scale) + _b(shift)
     if residual is not None:

@@ -192,9 +192,12 @@ def test_sliced_stem_5x7x7():
 @pytest.mark.parametrize("shape,relu,res", [((4, 24, 4, 8, 8), True, False),
                                             ((3, 10, 3, 5, 7), True, True),
                                             ((2, 64, 2, 4, 4), False, False),
-                                            # N*S > 16384: the streaming two-pass kernels
                                             ((4, 8, 8, 32, 32), True, False),
-                                            ((3, 6, 7, 30, 31), True, True)])
+                                            ((3, 6, 7, 30, 31), True, True),
+                                            ((3, 6, 7, 30, 31), True, False),
+                                            # N*S > 32768 per channel: the streaming two-pass kernels
+                                            ((2, 4, 16, 32, 40), True, False),
+                                            ((5, 3, 9, 31, 33), False, False)])
 def test_batchnorm_train_fwd_bwd(shape, relu, res):
     from coclr_amd import ops
     torch.manual_seed(4)
@@ -248,6 +251,18 @@ def test_batchnorm_train_fwd_bwd(shape, relu, res):
     close(dgb[1], beta.grad, rtol=5e-4, what="dbeta")
     if res:
         close(dres, resid.grad + 1.0, what="dres accumulate")
+    else:
+        # statistics + apply as ONE call (a single launch when a channel holds <= 32768 values,
+        # two launches above): identical result, running statistics advanced once
+        rm2, rv2 = dev(rm0), dev(rv0)
+        nbt2 = torch.zeros((), dtype=torch.long, device="cuda")
+        small2 = torch.empty(4, Cc, device="cuda")
+        wide2 = torch.zeros(N, Cc + 6, *shape[2:], device="cuda")
+        ops.bn_finalize_apply(dev(stats).contiguous(), Cc, 3, N * S, dev(gamma.detach()),
+                              dev(beta.detach()), rm2, rv2, nbt2, 0.1, 1e-5, small2[0], small2[1],
+                              small2[2], small2[3], yd, wide2[:, 3:3 + Cc], relu)
+        assert torch.equal(small2, small) and torch.equal(rm2, rmd) and torch.equal(rv2, rvd)
+        assert int(nbt2) == 1 and torch.equal(wide2, wide)
 
 
 def test_batchnorm_eval_affine():
