@@ -67,6 +67,7 @@ _SIGNATURES = {
     "coclr_queue_advance": [vp, i32, i32, vp],
     "coclr_positive_mask": [vp, vp, vp, vp, i32, i32, i32, vp],
     "coclr_gather_rows": [vp, vp, vp, i32, i64, i64, vp],
+    "coclr_pull_rows": [vp, vp, i32, i64, vp],
     "coclr_relu_fwd": [vp, vp, i64, vp],
     "coclr_relu_bwd": [vp, vp, vp, i64, vp],
     "coclr_colsum": [vp, vp, i32, i32, vp],

@@ -363,6 +363,24 @@ gather_rows_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx
   }
 }
 
+// out[i][:] = *rows[i]: every output row has its own source ADDRESS -- local memory or a peer GPU's
+// buffer mapped through hipIpc (xGMI reads): the shuffle-BN exchange as a row pull, each rank
+// fetching exactly the B clips it will encode (model/pretrain.py:98-124 gathers all B*world).
+__global__ void __launch_bounds__(256)
+pull_rows_kernel(const int64_t* __restrict__ rows, float* out, long row_elems) {
+  const long r = blockIdx.y;
+  const float* src = reinterpret_cast<const float*>(rows[r]);
+  float* dst = out + r * row_elems;
+  if ((row_elems & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+    const long n4 = row_elems >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+      reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_elems; i += (long)gridDim.x * 256)
+      dst[i] = src[i];
+  }
+}
+
 __global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
     y[e] = fmaxf(x[e], 0.f);
@@ -530,6 +548,18 @@ extern "C" int coclr_gather_rows(const float* in, const int64_t* idx, float* out
   if (gx > 256) gx = 256;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, in, idx,
                      out, (long)row_elems, (long)in_row_stride);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_pull_rows(const int64_t* row_ptrs, float* out, int rows, int64_t row_elems,
+                               void* stream) {
+  if (rows <= 0 || row_elems <= 0 || !row_ptrs || !out) return COCLR_EINVAL;
+  int gx = (int)((row_elems / 4 + 255) / 256);
+  if (gx < 1) gx = 1;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(pull_rows_kernel, dim3(gx, rows), dim3(256), 0, (hipStream_t)stream, row_ptrs,
+                     out, (long)row_elems);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

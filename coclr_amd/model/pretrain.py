@@ -27,7 +27,11 @@ from .. import optim as _optim
 from ..backbone.select_backbone import select_backbone
 
 _CHUNK = 32768   # elements per workgroup of the momentum kernel
-_ROUTED_SHUFFLE = os.environ.get("COCLR_SHUFFLE", "routed") != "allgather"
+# shuffle-BN exchange at world > 1: "routed" (RCCL all_to_all_single, default), "allgather" (the
+# reference's own scheme), "pull" (each rank reads its clips out of its peers' hipIpc-mapped staging
+# buffers with one HIP kernel; validated with two ranks on one GPU, opt-in until run over xGMI)
+_SHUFFLE_MODE = os.environ.get("COCLR_SHUFFLE", "routed")
+_ROUTED_SHUFFLE = _SHUFFLE_MODE != "allgather"
 _OVERLAP_KEYS = os.environ.get("COCLR_OVERLAP_KEYS", "1") != "0"
 _GRAPHS = os.environ.get("COCLR_GRAPHS", "1") != "0"
 
@@ -605,13 +609,88 @@ class InfoNCE(nn.Module):
         # them (shuffle gather, un-shuffle) before this forward returns, on this stream
         return recvbuf, n_index, idx_unshuffle
 
+    # -- shuffle-BN exchange as a peer row pull -----------------------------------------------
+    def _peer_stage(self, x2):
+        """Two staging buffers for this rank's key clips (double-buffered by step parity), mapped into
+        every peer process through hipIpc (torch's CUDA-IPC tensor sharing carries the handles over
+        the host channel).  Built once per input shape; a collective (every rank calls it)."""
+        world, rank = _world()
+        key = (tuple(x2.shape), x2.dtype, x2.device)
+        st = self.__dict__.get("_peer_stage_state")
+        if st is not None and st["key"] == key:
+            return st
+        from torch.multiprocessing.reductions import reduce_tensor
+        local = [torch.empty(x2.shape, dtype=x2.dtype, device=x2.device) for _ in range(2)]
+        torch.cuda.current_stream(x2.device).synchronize()
+        objs = [None] * world
+        dist.all_gather_object(objs, [reduce_tensor(t) for t in local], group=self._host_group())
+        peers = []
+        for r, lst in enumerate(objs):
+            if r == rank:
+                peers.append(local)
+            else:
+                mapped = [fn(*args) for fn, args in lst]
+                for t in mapped:
+                    if t.device != x2.device:
+                        t.reshape(-1)[:1].to(x2.device)      # makes torch enable peer access to it
+                peers.append(mapped)
+        B = x2.shape[0]
+        st = {"key": key, "local": local, "peers": peers, "step": 0,
+              "base": np.array([[t.data_ptr() for t in pr] for pr in peers], dtype=np.int64),
+              "row_bytes": x2[0].numel() * x2.element_size(),
+              "ident": torch.arange(B, device=x2.device),
+              "sync": torch.zeros(1, device=x2.device),
+              "host": None, "dev": None, "event": None}
+        self.__dict__["_peer_stage_state"] = st
+        return st
+
+    @torch.no_grad()
+    def _pull_shuffle(self, x2):
+        """Shuffle-BN input exchange (ref :98-124) as a row pull: every rank parks its B key clips
+        in a buffer its peers have mapped, and one HIP kernel (`coclr_pull_rows`) fetches the B clips
+        this rank has to encode straight from their owners -- B clips cross the fabric per rank, no
+        collective on the data path.  A one-element all-reduce is the stream-ordered barrier between
+        "everybody has parked" and "pull"; the staging buffers alternate by step, and the key
+        all-gather of the same step orders a peer's pull before this rank's next-but-one overwrite.
+        Returns (recv buffer, identity n_index, idx_unshuffle)."""
+        world, rank = _world()
+        B = x2.shape[0]
+        BW = B * world
+        st = self._peer_stage(x2)
+        par = st["step"] & 1
+        st["step"] += 1
+        perm = torch.randperm(BW)                         # same RNG use as the reference (:112)
+        dist.broadcast(perm, src=0, group=self._host_group())
+        pn = perm.numpy()
+        dev = x2.device
+        if st["host"] is None:
+            st["host"] = torch.empty(B + BW, dtype=torch.int64).pin_memory()
+            st["dev"] = torch.empty(B + BW, dtype=torch.int64, device=dev)
+        if st["event"] is not None:
+            st["event"].synchronize()
+        h = st["host"].numpy()
+        wanted = pn[rank * B:(rank + 1) * B]
+        h[:B] = st["base"][wanted // B, par] + (wanted % B) * st["row_bytes"]
+        h[B:] = np.argsort(pn, kind="stable")
+        st["dev"].copy_(st["host"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["event"] = ev
+        ops.gather_rows(x2, st["ident"], st["local"][par])       # park my clips (x2 is a strided view)
+        dist.all_reduce(st["sync"])                              # stream-ordered: everybody has parked
+        recv = torch.empty_like(st["local"][par])
+        ops.pull_rows(st["dev"][:B], recv, keep=st["peers"])
+        return recv, st["ident"], st["dev"][B:]
+
     @torch.no_grad()
     def _encode_keys(self, x2, pre=None):
         """Key path: [pre = momentum update] -> shuffle -> encoder_k -> normalise -> un-shuffle.
         Returns (k for this rank's samples, keys of the whole global batch in order)."""
         world, rank = _world()
         B = x2.shape[0]
-        if world > 1 and _ROUTED_SHUFFLE:
+        if world > 1 and _SHUFFLE_MODE == "pull":
+            src, n_index, idx_unshuffle = self._pull_shuffle(x2)
+        elif world > 1 and _ROUTED_SHUFFLE:
             src, n_index, idx_unshuffle = self._routed_shuffle(x2)
         elif world > 1:
             # the reference's own scheme (all-gather, keep B of B*world): COCLR_SHUFFLE=allgather

@@ -480,6 +480,14 @@ def gather_rows(inp, idx, out):
                "gather_rows")
 
 
+def pull_rows(row_ptrs, out, keep=None):
+    """out[i] = row at device address row_ptrs[i] (int64 tensor); `keep`: the (peer) tensors the
+    addresses point into, referenced while the launch is queued."""
+    rows = out.shape[0]
+    _lib.check(_L().coclr_pull_rows(_p(row_ptrs, torch.int64), _p(out), rows, out.numel() // rows,
+                                    _stream()), "pull_rows")
+
+
 def relu_fwd(x, y):
     _lib.check(_L().coclr_relu_fwd(_p(x), _p(y), x.numel(), _stream()), "relu_fwd")
 

@@ -248,6 +248,12 @@ int coclr_positive_mask(const float* sim, const int64_t* src, const int64_t* nam
 int coclr_gather_rows(const float* in, const int64_t* idx, float* out, int rows, int64_t row_elems,
                       int64_t in_row_stride, void* stream);
 
+/* out[i][:] = the `row_elems` floats at device address row_ptrs[i] (int64[rows] on the device): the
+ * shuffle-BN exchange of pretrain.py:98-124 as a ROW PULL -- each rank reads the B key clips it will
+ * encode straight out of its peers' staging buffers (hipIpc-mapped, over xGMI) instead of all-gathering
+ * B*world clips; local rows are ordinary addresses. */
+int coclr_pull_rows(const int64_t* row_ptrs, float* out, int rows, int64_t row_elems, void* stream);
+
 /* nn.ReLU of the projection head (pretrain.py:53) and small helpers. */
 int coclr_relu_fwd(const float* x, float* y, int64_t n, void* stream);
 int coclr_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);

@@ -325,6 +325,10 @@ def gather_rows(inp, idx, out):
     out.copy_(inp[idx])
 
 
+def pull_rows(row_ptrs, out, keep=None):
+    raise NotImplementedError("the peer row pull maps device memory across processes: GPU tier only")
+
+
 def relu_fwd(x, y):
     y.copy_(torch.relu(x))
 
