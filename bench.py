@@ -365,7 +365,7 @@ def main():
         issued = flops * 16.0 / 36.0                             # F(2x2,3x3): 16 of 36 products
         roof = None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath) and args.net == "s3d" and B == 32:
             # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
             # (counters cannot be read from inside the process)

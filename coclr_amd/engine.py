@@ -758,8 +758,14 @@ class EngineFn(torch.autograd.Function):
             raise RuntimeError("coclr_amd: backbone backward called twice (graph not retained)")
         ctx.run = None
         run.backward(dout)
-        dx = run.grads.get(id(ctx.xin.base)) if ctx.need_dx else None
-        grads = tuple(run.param_grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+        dx = run.grads.pop(id(ctx.xin.base), None) if ctx.need_dx else None
+        # Hand the gradients over WITHOUT keeping a reference: AccumulateGrad takes a freshly
+        # produced gradient as .grad only when nobody else holds it, and clones it otherwise --
+        # 235 extra copy launches per step when the run's tables still referenced them.
+        grads = tuple(run.param_grads.pop(id(p), None) if p.requires_grad else None
+                      for p in ctx.params)
+        run.param_grads.clear()
+        run.grads.clear()
         return (None, None, dx) + grads
 
 
