@@ -234,18 +234,28 @@ struct Wgrad2Args {
   int WT, WH, WW, plane1, plane, planeP;
   float inv_plane1, inv_hw, inv_ww;
   int ntiles, S;
+  int To_full;            // Winograd form: a.To counts frame PAIRS, this is the real frame count
 };
 
 __device__ __forceinline__ int w2_fdiv(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
 
-template <int KT, int KH, int KW, int MB, int NB, int PCH>
+//
+// WINO (temporal (3,1,1) stride-1 pad-1 stencils): Winograd F(2,3) along T, the form the forward
+// and data-gradient passes of these layers already use.  A box holds 32 frame PAIRS; per pair
+//     dU0 += dy0 (d0-d2)   dU1 += (dy0+dy1)(d1+d2)   dU2 += (dy0-dy1)(d2-d1)   dU3 += dy1 (d3-d1)
+// (d0..d3 = input frames 2p-1..2p+2): FOUR MFMAs per pair instead of the six of two direct
+// positions; the epilogue maps back dg0 = dU0 + (dU1+dU2)/2, dg1 = (dU1-dU2)/2,
+// dg2 = (dU1+dU2)/2 + dU3.  Seen from the code below it is a (4,1,1) stencil with temporal stride 2
+// over pair positions whose operands are sums / differences of two LDS reads.
+template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false>
 __global__ void __launch_bounds__(512)
 conv_wgrad2_kernel(const Wgrad2Args a) {
   constexpr int TAPS = KT * KH * KW;
-  constexpr int BP = 64;                 // positions per box
+  constexpr int BP = WINO ? 32 : 64;     // positions (WINO: frame pairs) per box
   constexpr int BMt = 64 * MB, BCt = 64 * NB;
-  constexpr int LDY = BP + 1;
+  constexpr int LDY = 64 + 1;            // WINO: [32 first frames | 32 second frames] per row
   constexpr int STEPS = BP / 2;
+  static_assert(!WINO || (KT == 4 && KH == 1 && KW == 1), "Winograd form is the (4,1,1)/2 view");
 
   extern __shared__ __align__(16) float smem[];
   const int planeP = a.planeP;
@@ -276,10 +286,12 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
         wn_[j] = q0; wt_[j] = t; wh_[j] = h; ww_[j] = q - h * a.WW;
       }
     }
-    const int ptw = lane & ((1 << lW) - 1);
-    const int pth = (lane >> lW) & ((1 << a.lTH) - 1);
-    const int ptt = (lane >> lWH) & ((1 << a.lTT) - 1);
-    const int ptn = lane >> lWHT;
+    const int plane_ = WINO ? (lane & 31) : lane;      // WINO: lanes 32-63 fetch the pair's 2nd frame
+    const int pfr = WINO ? (lane >> 5) : 0;
+    const int ptw = plane_ & ((1 << lW) - 1);
+    const int pth = (plane_ >> lW) & ((1 << a.lTH) - 1);
+    const int ptt = (plane_ >> lWH) & ((1 << a.lTT) - 1);
+    const int ptn = plane_ >> lWHT;
 
     for (int b = 0; b < nbox; ++b) {
       const int tile = split + b * a.S;
@@ -296,8 +308,9 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
       {
         const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.dy + (long)n0 * a.dy_nstride), 0, 0x80000000u, 0x00020000);
-        const int n = n0 + ptn, ot = ot0 + ptt, oh = oh0 + pth, ow = ow0 + ptw;
-        const bool ok = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
+        const int n = n0 + ptn, oh = oh0 + pth, ow = ow0 + ptw;
+        const int ot = WINO ? 2 * (ot0 + ptt) + pfr : ot0 + ptt;          // real output frame
+        const bool ok = n < a.N && ot < (WINO ? a.To_full : a.To) && oh < a.Ho && ow < a.Wo;
         const unsigned voff =
             ok ? (unsigned)(((long)ptn * a.dy_nstride + ((long)ot * a.Ho + oh) * a.Wo + ow) * 4)
                : W2_OOB;
@@ -382,11 +395,14 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
     const float* cur = smem + (b & 1) * stage_floats;
     __syncthreads();   // barrier b: box b is in LDS, box b-1 fully consumed
 
-    float av[2][MB], bv[2][NB][TAPS];
-    auto fetch = [&](int s, float (&A)[MB], float (&B)[NB][TAPS]) {
+    float av[2][MB], av1[2][MB], bv[2][NB][TAPS];
+    auto fetch = [&](int s, float (&A)[MB], float (&A1)[MB], float (&B)[NB][TAPS]) {
       const int wo = wo_of(s);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) A[mb] = cur[abase[mb] + 2 * s];
+      for (int mb = 0; mb < MB; ++mb) {
+        A[mb] = cur[abase[mb] + 2 * s];
+        if (WINO) A1[mb] = cur[abase[mb] + 32 + 2 * s];      // second frame of the pair
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int xb = jb[nb] + wo;
@@ -397,19 +413,37 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
         }
       }
     };
-    fetch(0, av[0], bv[0]);
+    fetch(0, av[0], av1[0], bv[0]);
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      if (s + 1 < STEPS) fetch(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+      if (s + 1 < STEPS) fetch(s + 1, av[(s + 1) & 1], av1[(s + 1) & 1], bv[(s + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
+      if (WINO) {
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t)
+        for (int mb = 0; mb < MB; ++mb) {
+          const float y0 = av[s & 1][mb], y1 = av1[s & 1][mb];
+          const float A4[4] = {y0, y0 + y1, y0 - y1, y1};
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+          for (int nb = 0; nb < NB; ++nb) {
+            const float d0 = bv[s & 1][nb][0], d1 = bv[s & 1][nb][1], d2 = bv[s & 1][nb][2],
+                        d3 = bv[s & 1][nb][3];
+            const float B4[4] = {d0 - d2, d1 + d2, d2 - d1, d3 - d1};
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                av[s & 1][mb], bv[s & 1][nb][t], acc[mb][nb][t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t)
+              acc[mb][nb][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A4[t], B4[t], acc[mb][nb][t],
+                                                                   0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                  av[s & 1][mb], bv[s & 1][nb][t], acc[mb][nb][t], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -426,9 +460,19 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
         for (int nb = 0; nb < NB; ++nb) {
           const int ci = ci0 + (wn * NB + nb) * 32 + l31;
           if (ci < a.Cin) {
-            float* dst = out + (long)co * a.J + ci * TAPS;
+            if (WINO) {
+              float* dst = out + (long)co * a.J + ci * 3;        // back to the three real taps
+              const float u0 = acc[mb][nb][0][i], u1 = acc[mb][nb][1][i], u2 = acc[mb][nb][2][i],
+                          u3 = acc[mb][nb][3][i];
+              const float hs = 0.5f * (u1 + u2);
+              dst[0] = u0 + hs;
+              dst[1] = 0.5f * (u1 - u2);
+              dst[2] = hs + u3;
+            } else {
+              float* dst = out + (long)co * a.J + ci * TAPS;
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) dst[t] = acc[mb][nb][t][i];
+              for (int t = 0; t < TAPS; ++t) dst[t] = acc[mb][nb][t][i];
+            }
           }
         }
       }
@@ -801,7 +845,7 @@ struct WPlan {
   ConvPlan p;
   int variant, BJ, S, jtiles, mtiles, planeP, pch, nci_max;
   // second-generation kernel
-  int v2;            // 0: not applicable, else variant id
+  int v2;            // 0: not applicable, else variant id (6: temporal Winograd form of id 2)
   int pw;            // pointwise: 16-byte-DMA GEMM kernel applicable
   ConvPlan p2;
   int S2, planeP2, mt2, ct2;
@@ -856,6 +900,32 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
   if (d->Cin < 8) return 0;
   ConvPlan& p = w->p2;
   conv_normalise(d, &p);
+  if (id == 2 && d->algo == 1 && d->st == 1 && d->pt == 1 && d->Ti == d->To && d->Cin >= 48 &&
+      d->Cout >= 48) {
+    // Winograd F(2,3) along T (the layer's forward / data gradient use it: desc.algo = 1): plan the
+    // (4,1,1) / stride-2 view over frame PAIRS, 32 pairs per box
+    ConvPlan q = p;
+    q.To = (p.To + 1) / 2;
+    q.st = 2;
+    conv_pick_box(&q, 5, 4, 1, 1);
+    const int planeP = q.plane | 1;
+    const size_t stage = ((size_t)64 * 65 + (size_t)64 * planeP) * sizeof(float);
+    const double lim = 2147483648.0;
+    if (q.lTW >= 1 && cdiv(q.plane, 64) <= 2 && 2 * stage <= 160 * 1024 &&
+        ((double)(1 << q.lTN) * d->x_nstride + (double)q.Cin * q.Ti * q.Hi * q.Wi) * 4.0 < lim &&
+        ((double)(1 << q.lTN) * d->y_nstride + (double)q.Cout * p.To * q.Ho * q.Wo) * 4.0 < lim) {
+      p = q;
+      w->planeP2 = planeP;
+      w->lds2 = 2 * stage;
+      w->mt2 = cdiv(p.Cout, 64);
+      w->ct2 = cdiv(p.Cin, 64);
+      int S = 512 / (w->mt2 * w->ct2);
+      if (S > p.ntiles / 4) S = p.ntiles / 4;
+      if (S < 1) S = 1;
+      w->S2 = S;
+      return 6;
+    }
+  }
   conv_pick_box(&p, 6, kt, kh, kw);
   if ((id == 4 || id == 5) && p.Ti == 1 && p.Hi == 1 && p.lTW == 6 && p.lTN == 0 &&
       (p.Wi % 64) == 0 && (d->x_nstride % 4) == 0 && (d->y_nstride % 4) == 0) {
@@ -933,9 +1003,9 @@ int launch_wgrad(WgradArgs& a, const WPlan& w, hipStream_t stream) {
   return 0;
 }
 
-template <int KT, int KH, int KW, int MB, int NB, int PCH>
+template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false>
 int launch_wgrad2(const Wgrad2Args& a, const WPlan& w, hipStream_t stream) {
-  auto kern = conv_wgrad2_kernel<KT, KH, KW, MB, NB, PCH>;
+  auto kern = conv_wgrad2_kernel<KT, KH, KW, MB, NB, PCH, WINO>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(512), w.lds2, stream, a);
@@ -981,6 +1051,8 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
     a.inv_hw = 1.0f / (float)(p.WH * p.WW);
     a.inv_ww = 1.0f / (float)p.WW;
     a.ntiles = p.ntiles; a.S = w.S2;
+    a.To_full = d->To;
+    if (w.v2 == 6) a.dy_cstride = d->To * p.Ho * p.Wo;     // p.To counts pairs there
     const int pch = cdiv(p.plane, 64);
     const bool pw = w.pw && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0;
     if (pw) {
@@ -1007,6 +1079,7 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
       case 3: rc = launch_wgrad2<7, 1, 1, 1, 1, 4>(a, w, stream); break;
       case 4: rc = launch_wgrad2<1, 1, 1, 2, 2, 2>(a, w, stream); break;
       case 5: rc = launch_wgrad2<1, 1, 1, 1, 1, 2>(a, w, stream); break;
+      case 6: rc = launch_wgrad2<4, 1, 1, 1, 1, 2, true>(a, w, stream); break;
       case 9: {
         auto kern = conv_wgrad_stem_kernel<7, 7, 3, 20>;
         static std::atomic<uint64_t> attr_done{0};

@@ -34,6 +34,7 @@ WGRAD_STREAM = os.environ.get("COCLR_WGRAD_STREAM", "1") != "0"
 # event latency than the overlap of the small branch kernels wins.  Off unless asked for.
 LANES = os.environ.get("COCLR_LANES", "0") == "1"
 _SIDE = {}
+_SIDE_PRIORITY = int(os.environ.get("COCLR_WGRAD_PRIORITY", "0"))
 _LANES = {}
 
 
@@ -300,7 +301,7 @@ class Run:
             return None
         st = _SIDE.get(self.device)
         if st is None:
-            st = _SIDE[self.device] = torch.cuda.Stream(device=self.device)
+            st = _SIDE[self.device] = torch.cuda.Stream(device=self.device, priority=_SIDE_PRIORITY)
         st.wait_stream(torch.cuda.current_stream(self.device))
         # Everything the side kernels read (the gradient dy AND the saved activation x) stays
         # referenced until join_side(): once a closure is popped its tensors would otherwise go

@@ -449,7 +449,8 @@ class InfoNCE(nn.Module):
             return None
         st = self.__dict__.get("_side_stream")
         if st is None or st.device != x.device:
-            st = torch.cuda.Stream(device=x.device)
+            st = torch.cuda.Stream(device=x.device,
+                                   priority=int(os.environ.get("COCLR_KEY_PRIORITY", "0")))
             self.__dict__["_side_stream"] = st
         st.wait_stream(torch.cuda.current_stream(x.device))
         return st

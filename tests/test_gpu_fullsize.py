@@ -75,12 +75,21 @@ def test_conv_adjoint_identities_every_s3d_layer_full_size():
         else:
             ops.conv_fwd(g.dgrad(), dy, run.pack(w, True), dx)
         e_d = abs(_dot(x, dx) - ref) / scale
-        # weight gradient
+        # weight gradient (direct form, and the form the engine's geometry selects when it differs:
+        # Winograd F(2,3) for the wide (3,1,1) layers)
         dw = torch.empty_like(w)
         ws = torch.empty(g.wgrad_workspace(), device="cuda")
         kk = k[0] * k[1] * k[2]
         ops.conv_wgrad(g, x, dy, dw, ws, cin * kk, kk, 0)
         e_w = abs(_dot(w, dw) - ref) / scale
+        ge = ops.conv_geom(B, cin, cout, idim, k, s, p)
+        if ge.algo != g.algo:
+            dw2 = torch.empty_like(w)
+            ws2 = torch.empty(ge.wgrad_workspace(), device="cuda")
+            ops.conv_wgrad(ge, x, dy, dw2, ws2, cin * kk, kk, 0)
+            e_w = max(e_w, abs(_dot(w, dw2) - ref) / scale)
+            e_w = max(e_w, float((dw2 - dw).abs().max() / dw.abs().max()) * 1e-2)   # elementwise 1e-3
+            del dw2, ws2
         worst = max(worst, e_d, e_w)
         # fp32 products summed over up to 1e9 terms: 1e-5 of the Cauchy-Schwarz scale
         assert e_d <= 1e-5 and e_w <= 1e-5, (cin, cout, idim, k, s, e_d, e_w)

@@ -525,7 +525,7 @@ def test_self_gating_kernels():
 
 WINO_CASES = [(2, 192, 192, (8, 8, 8)), (3, 208, 208, (4, 8, 8)), (2, 48, 48, (2, 4, 4)),
               (2, 64, 64, (3, 7, 7)), (2, 64, 96, (5, 6, 10)), (4, 32, 24, (16, 4, 4)),
-              (2, 128, 128, (1, 4, 4))]
+              (2, 128, 128, (1, 4, 4)), (3, 96, 80, (16, 16, 16)), (5, 70, 130, (7, 3, 5))]
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "%d_%d_%d_%s" % c)
@@ -559,6 +559,19 @@ def test_conv_temporal_winograd(case):
     dg = g.dgrad()
     ops.conv_fwd(dg, dyd, run.pack(wd, True, algo=1), dx)
     close(dx, x.grad, what="winograd dgrad")
+    # weight gradient: with desc.algo = 1 the wide layers (>= 48 channels both ways) take the
+    # Winograd F(2,3) form (four MFMAs per frame pair instead of six), the others the direct one
+    dw = torch.full_like(wd, float("nan"))
+    ws = torch.empty(g.wgrad_workspace(), device="cuda")
+    ops.conv_wgrad(g, xd, dyd, dw, ws, Cin * 3, 3, 0)
+    close(dw, w.grad, what="winograd wgrad")
+    ops.conv_wgrad(g, xd, dyd, dw, ws, Cin * 3, 3, 0, accumulate=True)
+    close(dw, 2 * w.grad, what="winograd wgrad accumulate")
+    # the same through a channel-slice view of a wider dY (concat-free inception gradients)
+    wide = torch.zeros(N, Cout + 5, *dims, device="cuda")
+    wide[:, 3:3 + Cout] = dyd
+    ops.conv_wgrad(g, xd, wide[:, 3:3 + Cout], dw, ws, Cin * 3, 3, 0)
+    close(dw, w.grad, what="winograd wgrad from a dY slice")
 
 
 WINO_HW_CASES = [(2, 64, 192, (2, 32, 32)), (2, 192, 208, (4, 16, 16)), (3, 48, 96, (3, 8, 8)),
