@@ -211,7 +211,8 @@ conv_wgrad_kernel(const WgradArgs a) {
 //     all taps.  (The first-generation kernel above maps lanes to (ci,tap) pairs and loses
 //     ~70 % of its LDS cycles to bank conflicts; it stays as the fallback for Cin = 3 and
 //     windows that do not fit two LDS stages.)
-//   * 512 threads: waves 0-3 only issue MFMAs, waves 4-7 only run the LDS-DMA engine
+//   * 512 threads (768 for the temporal forms, NL = 8): waves 0-3 only issue MFMAs, waves 4..3+NL
+//     only run the LDS-DMA engine
 //     (buffer_load_dword ... lds through bounds-checked descriptors: padding / overhang
 //     lanes land as 0.0).  Two LDS stages, ONE barrier per 64-position box: the loaders
 //     fill box b+1 while the matrix waves consume box b.
@@ -247,8 +248,8 @@ __device__ __forceinline__ int w2_fdiv(int e, float inv) { return (int)(((float)
 // positions; the epilogue maps back dg0 = dU0 + (dU1+dU2)/2, dg1 = (dU1-dU2)/2,
 // dg2 = (dU1+dU2)/2 + dU3.  Seen from the code below it is a (4,1,1) stencil with temporal stride 2
 // over pair positions whose operands are sums / differences of two LDS reads.
-template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false>
-__global__ void __launch_bounds__(512)
+template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false, int NL = 4>
+__global__ void __launch_bounds__(256 + 64 * NL)
 conv_wgrad2_kernel(const Wgrad2Args a) {
   constexpr int TAPS = KT * KH * KW;
   constexpr int BP = WINO ? 32 : 64;     // positions (WINO: frame pairs) per box
@@ -314,7 +315,7 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
         const unsigned voff =
             ok ? (unsigned)(((long)ptn * a.dy_nstride + ((long)ot * a.Ho + oh) * a.Wo + ow) * 4)
                : W2_OOB;
-        for (int row = lw; row < BMt; row += 4) {
+        for (int row = lw; row < BMt; row += NL) {
           const int co = co0 + row;
           if (co < a.Cout)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, LDS_PTR(dYs + row * LDY), 4, voff,
@@ -339,7 +340,7 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
                                      iw) * 4)
                        : W2_OOB;
         }
-        for (int c = lw; c < BCt; c += 4) {
+        for (int c = lw; c < BCt; c += NL) {
           const int ci = ci0 + c;
           if (ci < a.Cin) {
             const unsigned soff = (unsigned)ci * (unsigned)a.x_cstride * 4u;
@@ -1003,12 +1004,12 @@ int launch_wgrad(WgradArgs& a, const WPlan& w, hipStream_t stream) {
   return 0;
 }
 
-template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false>
+template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false, int NL = 4>
 int launch_wgrad2(const Wgrad2Args& a, const WPlan& w, hipStream_t stream) {
-  auto kern = conv_wgrad2_kernel<KT, KH, KW, MB, NB, PCH, WINO>;
+  auto kern = conv_wgrad2_kernel<KT, KH, KW, MB, NB, PCH, WINO, NL>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
-  hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(512), w.lds2, stream, a);
+  hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(256 + 64 * NL), w.lds2, stream, a);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
@@ -1075,11 +1076,15 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
     switch (w.v2) {
       case 1: rc = pch <= 2 ? launch_wgrad2<1, 3, 3, 1, 1, 2>(a, w, stream)
                             : launch_wgrad2<1, 3, 3, 1, 1, 3>(a, w, stream); break;
-      case 2: rc = launch_wgrad2<3, 1, 1, 1, 1, 2>(a, w, stream); break;
+      // the temporal forms are loader-bound with four loader waves (3 or 4 MFMAs per four LDS-DMA
+      // pieces): EIGHT loader waves beside the four matrix waves (768 threads; 48-64 accumulator
+      // registers leave room for three waves per SIMD): direct 1.20 -> 1.05 ms, Winograd 1.07 ->
+      // 0.90 ms on Conv_2c.conv2.  (7,1,1) (112 accumulators) and (1,3,3) (144) keep four.
+      case 2: rc = launch_wgrad2<3, 1, 1, 1, 1, 2, false, 8>(a, w, stream); break;
       case 3: rc = launch_wgrad2<7, 1, 1, 1, 1, 4>(a, w, stream); break;
       case 4: rc = launch_wgrad2<1, 1, 1, 2, 2, 2>(a, w, stream); break;
       case 5: rc = launch_wgrad2<1, 1, 1, 1, 1, 2>(a, w, stream); break;
-      case 6: rc = launch_wgrad2<4, 1, 1, 1, 1, 2, true>(a, w, stream); break;
+      case 6: rc = launch_wgrad2<4, 1, 1, 1, 1, 2, true, 8>(a, w, stream); break;
       case 9: {
         auto kern = conv_wgrad_stem_kernel<7, 7, 3, 20>;
         static std::atomic<uint64_t> attr_done{0};
