@@ -174,7 +174,13 @@ class Adam(_TorchAdam):
                 loss = closure()
         groups = self._native_groups()
         if groups is None:
-            self._plan = None
+            if self._plan is not None:
+                # leaving the single-launch path (e.g. a sparse gradient appeared): torch's own
+                # implementation wants its per-parameter step counters on the host
+                for st in self.state.values():
+                    if torch.is_tensor(st.get("step")) and st["step"].is_cuda:
+                        st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+                self._plan = None
             super().step()
             return loss
         params = [p for _, ps in groups for p in ps]

@@ -329,3 +329,32 @@ def test_nn_retrieval_matches_reference():
     assert torch.equal(top.cpu().long(), ti)
     for i, k in enumerate((1, 5, 20)):
         assert torch.equal(hits[:, i].cpu(), (trl[ti[:, :k]] == tel[:, None]).any(1).float())
+
+
+def test_adam_leaves_and_reenters_the_native_path():
+    """A step the kernel does not cover (here: amsgrad switched on for one group) runs torch's own
+    implementation on the same state, and the next covered step picks the state up again."""
+    from coclr_amd import optim as O
+    torch.manual_seed(0)
+    ps = [torch.randn(100, device="cuda", requires_grad=True), torch.randn(7, 3, device="cuda", requires_grad=True)]
+    ref_ps = [p.detach().cpu().clone().requires_grad_(True) for p in ps]
+    opt = O.Adam([{"params": p} for p in ps], lr=1e-2)
+    ref = O._TorchAdam([{"params": p} for p in ref_ps], lr=1e-2)
+    gen = torch.Generator().manual_seed(1)
+
+    def step(native_expected):
+        for p, rp in zip(ps, ref_ps):
+            g = torch.randn(rp.shape, generator=gen)
+            p.grad, rp.grad = g.cuda(), g.clone()
+        opt.step()
+        ref.step()
+        assert (opt._plan is not None) == native_expected
+        for p, rp in zip(ps, ref_ps):
+            check_close(p, rp, 2e-6, "parameter")
+
+    step(True)
+    opt.param_groups[0]["foreach"] = True         # an explicit torch path: not ours
+    step(False)
+    opt.param_groups[0]["foreach"] = None
+    step(True)
+    assert float(opt.state[ps[0]]["step"]) == 3.0
