@@ -7,6 +7,7 @@ ATen, and there is no CPU path: host tensors are rejected.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -15,6 +16,20 @@ from ._lib import ConvDesc, PoolDesc
 
 
 _HANDLE = None
+_MAIN_THREAD = threading.get_ident()
+
+
+def _desc(geom):
+    """The launch descriptor of a cached geometry that THIS thread may fill in (strides, sample
+    count): geometries are shared and cached, and the forward (caller's thread) and the backward
+    (autograd's device thread) of different tensors may use one at the same time -- each side
+    writes its own copy."""
+    if threading.get_ident() == _MAIN_THREAD:
+        return geom.desc
+    d = geom.desc_bw
+    if d is None:
+        d = geom.desc_bw = type(geom.desc).from_buffer_copy(geom.desc)
+    return d
 
 
 def _L():
@@ -86,7 +101,7 @@ class ConvGeom:
     """Geometry of one 3D convolution (python mirror of coclr_conv_desc)."""
 
     __slots__ = ("N", "Cin", "Cout", "idim", "odim", "k", "s", "p", "d", "lattice", "algo", "desc",
-                 "_cache")
+                 "desc_bw", "_cache")
 
     def __init__(self, N, Cin, Cout, idim, k, s, p, d=(1, 1, 1), odim=None, lattice=None, algo=0):
         self.N, self.Cin, self.Cout = int(N), int(Cin), int(Cout)
@@ -113,6 +128,7 @@ class ConvGeom:
             raise ValueError("coclr_amd: Winograd needs a (3,1,1) or (1,3,3) stride-1 'same' stencil")
         self.desc = ConvDesc(self.N, self.Cin, self.Cout, *self.idim, *self.odim, *self.k,
                              *self.s, *self.p, *self.d, 0, 0, *lat, 0, self.algo)
+        self.desc_bw = None
         self._cache = {}
 
     @property
@@ -217,7 +233,7 @@ def pool_geom(N, Cc, idim, k, s, p):
 
 
 class PoolGeom:
-    __slots__ = ("N", "C", "idim", "odim", "k", "s", "p", "desc")
+    __slots__ = ("N", "C", "idim", "odim", "k", "s", "p", "desc", "desc_bw")
 
     def __init__(self, N, Cc, idim, k, s, p):
         self.N, self.C = int(N), int(Cc)
@@ -228,6 +244,7 @@ class PoolGeom:
         if min(self.odim) <= 0:
             raise ValueError("coclr_amd: pooling output would be empty")
         self.desc = PoolDesc(self.N, self.C, *self.idim, *self.odim, *self.k, *self.s, *self.p, 0, 0)
+        self.desc_bw = None
 
 
 # ---- convolution ---------------------------------------------------------------
@@ -279,7 +296,7 @@ def conv_pack_batch(table, blockmap, requests=None):
 
 def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shift=None,
              n_index=None, relu=False, accumulate=False):
-    d = geom.desc
+    d = _desc(geom)
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(y, "y")
     d.Nx = x.shape[0]
@@ -289,7 +306,7 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
 
 
 def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accumulate=False):
-    d = geom.desc
+    d = _desc(geom)
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(dy, "dy")
     _lib.check(_L().coclr_conv3d_wgrad(
@@ -367,7 +384,7 @@ def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dga
 def maxpool_fwd(geom, x, y, indices=None, in_scale=None, in_shift=None, in_relu=False):
     """in_scale / in_shift: per-channel affine (+ ReLU) applied to x as it is read -- the pool then
     consumes the RAW convolution output of the BatchNorm unit in front of it."""
-    d = geom.desc
+    d = _desc(geom)
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(y, "y")
     _lib.check(_L().coclr_maxpool3d_fwd(C.byref(d), _p(x), _p(y), _p(indices, torch.int32),
@@ -377,7 +394,7 @@ def maxpool_fwd(geom, x, y, indices=None, in_scale=None, in_shift=None, in_relu=
 
 def maxpool_bwd(geom, dy, indices, dx, accumulate=False):
     _lib.check(_L().coclr_maxpool3d_bwd(
-        C.byref(geom.desc), _p(dy), _p(indices, torch.int32), _p(dx), _chk5(dy, "dy"),
+        C.byref(_desc(geom)), _p(dy), _p(indices, torch.int32), _p(dx), _chk5(dy, "dy"),
         _chk5(dx, "dx"), int(accumulate), _stream()), "maxpool3d_bwd")
 
 
