@@ -407,15 +407,40 @@ class InfoNCE(nn.Module):
     @torch.no_grad()
     def _shuffle_indices(self, batch_size_this, device):
         """Common permutation of the global batch: CPU randperm (same RNG stream as the
-        reference, ref :112) broadcast from rank 0."""
+        reference, ref :112) broadcast from rank 0.  At world size 1 permutation and inverse are
+        formed on the host and reach the device through a pinned double buffer with ONE
+        non-blocking copy: a pageable `.to(device)` would make the host wait, at the start of every
+        forward, for everything the previous step still has queued."""
         world, rank = _world()
         batch_size_all = batch_size_this * world
-        idx_shuffle = torch.randperm(batch_size_all).to(device)
-        if world > 1:
-            dist.broadcast(idx_shuffle, src=0)
-        idx_unshuffle = torch.argsort(idx_shuffle)
-        idx_this = idx_shuffle.view(world, -1)[rank]
-        return idx_this, idx_unshuffle
+        perm = torch.randperm(batch_size_all)
+        if world > 1 or device.type != "cuda":
+            idx_shuffle = perm.to(device)
+            if world > 1:
+                dist.broadcast(idx_shuffle, src=0)
+            idx_unshuffle = torch.argsort(idx_shuffle)
+            return idx_shuffle.view(world, -1)[rank], idx_unshuffle
+        st = self.__dict__.get("_perm_staging")
+        if st is None or st["n"] != batch_size_all or st["dev"][0].device != device:
+            st = self.__dict__["_perm_staging"] = {
+                "n": batch_size_all, "flip": 0, "events": [None, None],
+                "host": [torch.empty(2 * batch_size_all, dtype=torch.int64).pin_memory()
+                         for _ in range(2)],
+                "dev": [torch.empty(2 * batch_size_all, dtype=torch.int64, device=device)
+                        for _ in range(2)]}
+        f = st["flip"]
+        st["flip"] = 1 - f
+        if st["events"][f] is not None:
+            st["events"][f].synchronize()            # the copy issued two steps ago
+        h = st["host"][f].numpy()
+        pn = perm.numpy()
+        h[:batch_size_all] = pn
+        h[batch_size_all:] = np.argsort(pn, kind="stable")
+        st["dev"][f].copy_(st["host"][f], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][f] = ev
+        return st["dev"][f][:batch_size_all], st["dev"][f][batch_size_all:]
 
     @torch.no_grad()
     def _batch_shuffle_ddp(self, x):
