@@ -233,7 +233,7 @@ def main():
         ddp = nn.parallel.DistributedDataParallel(model)
     else:
         model = model.cuda(local_rank)
-        ddp = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+        ddp = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])   # main_nce.py:172
     # main_nce.py:190-200: one param group per tensor, frozen ones included
     groups = [{"params": p} for _, p in ddp.named_parameters()]
     opt = torch.optim.Adam(groups, lr=1e-3, weight_decay=1e-5)
@@ -431,6 +431,10 @@ def main():
                        "optimizer": "coclr_amd.optim.Adam (torch.optim.Adam resolved by the "
                                     "model.pretrain shim): one launch per step",
                        "loss": "coclr_amd.loss (loss + top-1/top-5 in one pass, device scalars)",
+                       "ddp": "DistributedDataParallel(model, device_ids=[gpu]) as main_nce.py:172; "
+                              "gradient_as_bucket_view=%s (the shim's default for this model, "
+                              "COCLR_PATCH_DDP=0 restores torch's False: about -3 %%)"
+                              % getattr(ddp, "gradient_as_bucket_view", None),
                        "excluded_caller_work": "meters' .item() syncs, dataloader + H2D",
                        "final_loss": round(final_loss, 4)},
             "roofline": roof, "roofline_hbm": roof_hbm, "roofline_nce": nce,

@@ -215,3 +215,26 @@ def test_retrieval_host_logic(fake):
     assert topidx.shape == (g["test_feature"].shape[0], 50)
     with pytest.raises(ValueError):
         nn_retrieval(g["test_feature"], g["test_label"], g["train_feature"], g["train_label"], ks=(5, 1))
+
+
+def test_ddp_default_for_this_model_only():
+    """The shim flips DistributedDataParallel's `gradient_as_bucket_view` default to True for the
+    InfoNCE / UberNCE / CoCLR modules only, and never overrides an explicit argument."""
+    import os
+    import torch.distributed as dist
+    import model.pretrain as product
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29741")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        DDP = torch.nn.parallel.DistributedDataParallel
+        torch.manual_seed(0)
+        m = product.InfoNCE('s3d', 128, 32, 0.999, 0.07)
+        assert DDP(m).gradient_as_bucket_view is True
+        assert DDP(m, gradient_as_bucket_view=False).gradient_as_bucket_view is False
+        assert DDP(torch.nn.Linear(3, 3)).gradient_as_bucket_view is False
+    finally:
+        if own:
+            dist.destroy_process_group()
