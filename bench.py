@@ -321,6 +321,19 @@ def main():
                           "nn.functional.cross_entropy, everything else identical" % len(groups)}
         cur = opt
 
+    # ---- host floor: the same step on 4 clips per GPU, where the GPU is never the bottleneck -----------
+    host_floor = None
+    if not args.no_extra_legs and args.model == "infonce" and B >= 16:
+        small = [[blk[:4].contiguous() for blk in blks] for blks in pool]
+        big_pool, pool = pool, small
+        for i in range(4):
+            step(i)
+        nf = 12           # 16 small steps in all: the queue pointer is back on the big batch's grid
+        dtf, _, _, _ = timed_run(nf, True)
+        host_floor = round(dtf / nf * 1e3, 2)
+        pool = big_pool
+        step(0)                                   # back to the benchmark shape (graphs are kept per shape)
+
     # ---- isolated micro-runs on rank 0: the dominant kernel, the largest BN apply, the NCE GEMM ------
     iso_ms = bn_iso_ms = None
     nce = None
@@ -440,6 +453,10 @@ def main():
             "roofline": roof, "roofline_hbm": roof_hbm, "roofline_nce": nce,
             "step_roofline": step_view,
             "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 2),
+            "host_floor_ms_per_step": host_floor,
+            "host_note": "host_enqueue includes the time the host sits in a launch because the hardware "
+                         "queue is full (no synchronising call inside a step, tools/find_syncs.py); "
+                         "host_floor = the same step at 4 clips/GPU, where only the host paces it",
             "abi_calls_per_step": round(calls_per_step, 1),
         }
         if caller is not None:
