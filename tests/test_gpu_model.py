@@ -171,6 +171,9 @@ def test_graph_replay_matches_eager():
     must agree bit for bit -- every kernel on this path is deterministic."""
     import copy
     import model.pretrain as product
+    import coclr_amd.model.pretrain as impl
+    if not impl._GRAPHS:
+        pytest.skip("hipGraph replay switched off by COCLR_GRAPHS=0")
     gold = load_golden("infonce_s3d_small")
     cfg = gold["cfg"]
     base = build_model(cfg, product)
