@@ -35,6 +35,7 @@ WGRAD_STREAM = os.environ.get("COCLR_WGRAD_STREAM", "1") != "0"
 LANES = os.environ.get("COCLR_LANES", "0") == "1"
 _SIDE = {}
 _SIDE_PRIORITY = int(os.environ.get("COCLR_WGRAD_PRIORITY", "0"))
+_SIDE_WINDOW = 12     # weight-gradient closures per release window (Run.side_stream)
 _LANES = {}
 
 
@@ -194,6 +195,8 @@ class Run:
         self.batched = False   # the plan's launch has re-laid its operands for this pass
         self._side_used = False
         self._side_keep = []   # tensors read by side-stream kernels, released at join_side()
+        self._side_windows = []   # [(side-stream event, tensors enqueued before it)]
+        self._side_calls = 0
         if device.type == "cuda" and device.index is not None and \
                 device.index != torch.cuda.current_device():
             # kernels are enqueued on the CURRENT device's current stream (ops._stream)
@@ -308,6 +311,18 @@ class Run:
         # back to the main stream's allocator pool and could be handed out again while a lagging
         # weight-gradient kernel still reads them.  Holding the references is cheaper on the host
         # than record_stream (no event queries at free time) and bounded by one backward pass.
+        # ... in windows: every _SIDE_WINDOW calls an event on the side stream closes the window
+        # of everything enqueued there so far; windows whose event has completed drop their
+        # references (one event query per window, so the host cost stays negligible while the
+        # peak is activations + a few windows of dy instead of activations + ALL dy).
+        self._side_calls += 1
+        if self._side_calls % _SIDE_WINDOW == 0 and self._side_keep:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._side_windows.append((ev, self._side_keep))
+            self._side_keep = []
+            while self._side_windows and self._side_windows[0][0].query():
+                self._side_windows.pop(0)
         self._side_keep.extend(inputs)
         self._side_used = True
         return st
@@ -317,6 +332,7 @@ class Run:
             torch.cuda.current_stream(self.device).wait_stream(_SIDE[self.device])
             self._side_used = False
         self._side_keep = []
+        self._side_windows = []
 
     # -- weight packing ------------------------------------------------------------
     def _packed_buffer(self, owner, tag, n, zero):

@@ -68,8 +68,9 @@ class Adam(_TorchAdam):
                 if gr is None:
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or gr.is_sparse or \
-                        gr.dtype != torch.float32 or not p.is_contiguous():
-                    return None
+                        gr.dtype != torch.float32 or not p.is_contiguous() or \
+                        not gr.is_contiguous() or gr.device != p.device:
+                    return None       # the kernel reads p and p.grad as flat fp32 memory
                 if dev is None:
                     dev = p.device
                 elif p.device != dev:
@@ -113,10 +114,11 @@ class Adam(_TorchAdam):
             for model in list(_MOMENTUM_MODELS):
                 pq = [p for p in model.encoder_q.parameters()]
                 pk = [p for p in model.encoder_k.parameters()]
-                need = [p for p in pq if p.requires_grad]
-                if need and all(id(p) in have for p in need) and \
+                # every (query, key) pair must be folded, or none: the model skips its own update
+                # once the optimiser says it has applied it
+                if pq and all(p.requires_grad and id(p) in have for p in pq) and \
                         all(k.is_cuda and k.is_contiguous() for k in pk):
-                    kptr = {id(q): k for q, k in zip(pq, pk) if q.requires_grad}
+                    kptr = {id(q): k for q, k in zip(pq, pk)}
                     fold = weakref.ref(model)
                     break
         rows, row_param, row_off = [], [], []
@@ -143,7 +145,10 @@ class Adam(_TorchAdam):
             # parameter): hyper rows are the group's values repeated per parameter
             "hyper": torch.empty(n, 8, dtype=torch.float64, device=dev), "hyper_sig": None,
             "ids": torch.arange(n, dtype=torch.int32, device=dev), "n": n,
-            "sig": [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr()) for p in params],
+            "sig": [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                     self.state[p]["exp_avg_sq"].data_ptr(),
+                     0 if kptr.get(id(p)) is None else kptr[id(p)].data_ptr()) for p in params],
+            "kparams": [kptr.get(id(p)) for p in params],
             "fold": fold,
             "keep": [self.state[p]["exp_avg"] for p in params] +
                     [self.state[p]["exp_avg_sq"] for p in params] + list(kptr.values()),
@@ -156,11 +161,12 @@ class Adam(_TorchAdam):
             return False
         state = self.state
         steps_ptr = plan["steps"].untyped_storage().data_ptr()
-        for a, b, (pp, mp) in zip(plan["params"], params, plan["sig"]):
-            if a is not b or b.data_ptr() != pp:
+        for a, b, (pp, mp, vp, kp), k in zip(plan["params"], params, plan["sig"], plan["kparams"]):
+            if a is not b or b.data_ptr() != pp or (k is not None and k.data_ptr() != kp):
                 return False
             st = state[b]
-            if not st or st["exp_avg"].data_ptr() != mp or not torch.is_tensor(st["step"]) or \
+            if not st or st["exp_avg"].data_ptr() != mp or st["exp_avg_sq"].data_ptr() != vp or \
+                    not torch.is_tensor(st["step"]) or \
                     st["step"].untyped_storage().data_ptr() != steps_ptr:
                 return False
         return True
@@ -231,4 +237,8 @@ def install():
         return False
     if torch.optim.Adam is not Adam:
         torch.optim.Adam = Adam
+        if os.environ.get("COCLR_QUIET", "0") != "1":
+            import sys
+            print("coclr_amd: torch.optim.Adam resolves to the single-launch subclass "
+                  "(COCLR_PATCH_ADAM=0 opts out)", file=sys.stderr)
     return True

@@ -10,12 +10,23 @@ The flag only constrains callers that `detach_()` gradients; the launch scripts 
 `.grad` (they call `zero_grad()`, `backward()`, `step()`), so for modules of THIS package the shim
 makes True the default when the caller did not say otherwise.  `COCLR_PATCH_DDP=0` opts out.
 """
+import inspect
 import os
+import sys
 
 import torch
 
 _DDP = torch.nn.parallel.DistributedDataParallel
-_POS = 9           # index of gradient_as_bucket_view among the positional arguments after `module`
+
+
+def _positional_index():
+    """Index of gradient_as_bucket_view among the positional arguments after `module` (9 on torch
+    >= 2.4, which has init_sync in front of it; 8 before)."""
+    names = [n for n in inspect.signature(_DDP.__init__).parameters if n not in ("self", "module")]
+    return names.index("gradient_as_bucket_view")
+
+
+_POS = _positional_index()
 _installed = [False]
 
 
@@ -35,4 +46,7 @@ def install(module_types):
     __init__.__doc__ = orig.__doc__
     _DDP.__init__ = __init__
     _installed[0] = True
+    if os.environ.get("COCLR_QUIET", "0") != "1":
+        print("coclr_amd: DistributedDataParallel defaults to gradient_as_bucket_view=True for "
+              "InfoNCE/UberNCE/CoCLR modules (COCLR_PATCH_DDP=0 opts out)", file=sys.stderr)
     return True

@@ -54,6 +54,7 @@ class ClipStager:
         self.pinned = [None, None]
         self.staged = [None, None]
         self.done = [None, None]
+        self.read_done = [None, None]      # main-stream event: the kernel that last READ staged[f]
         self.flip = 0
 
     def __call__(self, frames):
@@ -74,11 +75,17 @@ class ClipStager:
             if self.staged[f] is None or self.staged[f].shape != frames.shape or \
                     self.staged[f].dtype != frames.dtype:
                 self.staged[f] = torch.empty(frames.shape, dtype=frames.dtype, device=self.device)
-            else:
-                self.copy_stream.wait_stream(main)       # the kernel that last read this buffer
+            elif self.read_done[f] is not None:
+                # only the kernel that last read THIS buffer (two calls ago), not everything the
+                # main stream has queued since: the transfer of batch i+1 runs under step i
+                self.copy_stream.wait_event(self.read_done[f])
             self.staged[f].copy_(frames, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             self.done[f] = ev
         main.wait_stream(self.copy_stream)
-        return tr(self.staged[f], self.num_seq, self.seq_len, self.mean, self.std)
+        out = tr(self.staged[f], self.num_seq, self.seq_len, self.mean, self.std)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.read_done[f] = ev
+        return out
