@@ -295,30 +295,40 @@ class InfoNCE(nn.Module):
     def _ddp_params_and_buffers_to_ignore(self):
         """DistributedDataParallel skips the buffers named here (it reads this attribute at
         wrap time).  The model keeps ALL its buffers (BN statistics of three encoders, the
-        queues, the pointer) as views of one flat allocation and broadcasts that from rank 0
-        itself at the start of every forward -- the semantics of the reference's
-        DDP(broadcast_buffers=True) (main_nce.py:172) as ONE
-        collective instead of ~470 tensor copies into and out of a coalescing buffer."""
+        queues, the pointer) as views of one flat allocation per dtype and broadcasts those from
+        rank 0 itself at the start of every forward -- the semantics of the reference's
+        DDP(broadcast_buffers=True) (main_nce.py:172) as TWO
+        collectives instead of ~470 tensor copies into and out of a coalescing buffer."""
         return [n for n, _ in self.named_buffers()]
 
     def _flatten_buffers(self):
+        """One allocation PER DTYPE (fp32: BN statistics and the queues; int64: counters, pointer,
+        name / label queues).  Not one for everything: torch.save refuses tensors of different dtypes
+        that view one storage, and the launch scripts checkpoint `state_dict()` as it is
+        (main_nce.py:278-290)."""
         seen, entries = set(), []
         for mod in self.modules():
             for key, b in mod._buffers.items():
                 if b is not None and id(b) not in seen:
                     seen.add(id(b))
                     entries.append((mod, key, b))
-        offs, total = [], 0
-        for _, _, b in entries:
-            offs.append(total)
-            total += (b.numel() * b.element_size() + 15) // 16 * 16
-        flat = torch.empty(total, dtype=torch.uint8, device=self.queue.device)
-        with torch.no_grad():
-            for (mod, key, b), off in zip(entries, offs):
-                v = flat[off:off + b.numel() * b.element_size()].view(b.dtype).view(b.shape)
-                v.copy_(b)
-                mod._buffers[key] = v
-        self.__dict__["_flat_buffers"] = flat
+        flats = []
+        for dtype in sorted({b.dtype for _, _, b in entries}, key=str):
+            mine = [(mod, key, b) for mod, key, b in entries if b.dtype == dtype]
+            esz = mine[0][2].element_size()
+            pad = max(1, 16 // esz)
+            offs, total = [], 0
+            for _, _, b in mine:
+                offs.append(total)
+                total += (b.numel() + pad - 1) // pad * pad
+            flat = torch.empty(total, dtype=dtype, device=self.queue.device)
+            with torch.no_grad():
+                for (mod, key, b), off in zip(mine, offs):
+                    v = flat[off:off + b.numel()].view(b.shape)
+                    v.copy_(b)
+                    mod._buffers[key] = v
+            flats.append(flat)
+        self.__dict__["_flat_buffers"] = flats
 
     def _sync_buffers(self):
         dev = self.queue.device
@@ -326,19 +336,22 @@ class InfoNCE(nn.Module):
             # every kernel is enqueued on the current device's current stream (ops._stream)
             raise RuntimeError("coclr_amd: model lives on %s but the current device is cuda:%d; "
                                "call torch.cuda.set_device first" % (dev, torch.cuda.current_device()))
-        flat = self.__dict__.get("_flat_buffers")
-        if flat is None or flat.device != self.queue.device or \
-                self.queue.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr() or \
-                self.queue_ptr.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
+        flats = self.__dict__.get("_flat_buffers")
+        if flats is not None:
+            ptrs = {f.untyped_storage().data_ptr() for f in flats}
+        if flats is None or flats[0].device != self.queue.device or \
+                self.queue.untyped_storage().data_ptr() not in ptrs or \
+                self.queue_ptr.untyped_storage().data_ptr() not in ptrs:
             self._flatten_buffers()       # first use, or .cuda()/.to() re-created the buffers
-            flat = self.__dict__["_flat_buffers"]
+            flats = self.__dict__["_flat_buffers"]
         world, _ = _world()
         if world > 1:
             # new_group is a collective: every rank creates the host-side channel HERE, at its first
             # forward, whatever shuffle scheme / train-or-eval path it takes afterwards
             self._host_group()
             with torch.no_grad():
-                dist.broadcast(flat, src=0)
+                for flat in flats:
+                    dist.broadcast(flat, src=0)
 
     # -- momentum encoder ---------------------------------------------------------
     def _build_momentum_table(self):
@@ -514,7 +527,7 @@ class InfoNCE(nn.Module):
         params = encoder.__dict__.get("_coclr_plist")
         if params is None:
             params = encoder.__dict__["_coclr_plist"] = list(encoder.parameters())
-        flat = self.__dict__.get("_flat_buffers")
+        flats = self.__dict__.get("_flat_buffers")
         # One cache entry per (encoder, BN mode, with/without the momentum prologue): toggling
         # train()/eval() or no_grad switches between captured graphs instead of re-capturing.
         key = (id(encoder), encoder.training, encoder[0].training, pre is not None)
@@ -522,7 +535,7 @@ class InfoNCE(nn.Module):
         # (encoder parameters, the flat buffer allocation, and -- for the momentum prologue -- the
         # query parameters and m itself, which the kernel receives as constants).
         sig = (tuple(src.shape[1:]), int(n_index.shape[0]), src.dtype, dev, params[0].data_ptr(),
-               params[-1].data_ptr(), 0 if flat is None else flat.data_ptr())
+               params[-1].data_ptr(), () if flats is None else tuple(f.data_ptr() for f in flats))
         if pre is not None:
             qps = self.encoder_q.__dict__.get("_coclr_plist")
             if qps is None:

@@ -23,6 +23,8 @@ def _positional_index():
     """Index of gradient_as_bucket_view among the positional arguments after `module` (9 on torch
     >= 2.4, which has init_sync in front of it; 8 before)."""
     names = [n for n in inspect.signature(_DDP.__init__).parameters if n not in ("self", "module")]
+    if "gradient_as_bucket_view" not in names:      # somebody wrapped __init__ with (*args, **kwargs)
+        return 9
     return names.index("gradient_as_bucket_view")
 
 

@@ -1,7 +1,7 @@
 """Parity at BASELINE.json's FULL sizes (B=32 clips of 3x32x128x128, K=16384) through
 size-independent properties -- the CPU oracle would need ~20 s per step there:
 
-  * every convolution geometry of the S3D backbone: the adjoint identities
+  * every convolution geometry of the S3D and ResNet2d3d-50 backbones: the adjoint identities
         <conv(x, w), dy> == <x, dgrad(dy, w)> == <w, wgrad(x, dy)>
     tie the three kernels (forward / data gradient incl. the phase-decomposed strided form /
     weight gradient incl. split-K) to each other; the forward itself is pinned to the oracle at
@@ -23,16 +23,17 @@ def _dot(a, b):
     return float((a.double() * b.double()).sum())
 
 
-def _s3d_geometries():
-    """Unique (conv geometry, is-first-layer) pairs of one S3D forward at the benchmark shape,
-    recorded from the engine itself."""
+def _geometries(network):
+    """Unique conv geometries of one backbone forward at the benchmark shape, recorded from the
+    engine itself (so strided 1x1x1 downsamples appear as the dense pointwise convs they run as and
+    r50's (5,7,7) stem as its five per-tap (1,7,7) launches with their shifted padding)."""
     from coclr_amd import ops
     from backbone.select_backbone import select_backbone
     seen, order = set(), []
     inner = ops.conv_fwd
 
     def rec(geom, *a, **kw):
-        key = (geom.Cin, geom.Cout, geom.idim, geom.k, geom.s, geom.p)
+        key = (geom.Cin, geom.Cout, geom.idim, geom.k, geom.s, geom.p, geom.odim)
         if key not in seen:
             seen.add(key)
             order.append(key)
@@ -41,24 +42,29 @@ def _s3d_geometries():
     ops.conv_fwd = rec
     try:
         torch.manual_seed(0)
-        net, _ = select_backbone("s3d")
+        net, _ = select_backbone(network)
         net = net.cuda().train()
         with torch.no_grad():
             net(torch.randn(B, 3, 32, 128, 128, device="cuda"))
     finally:
         ops.conv_fwd = inner
+    del net
+    torch.cuda.empty_cache()
     return order
 
 
-def test_conv_adjoint_identities_every_s3d_layer_full_size():
+@pytest.mark.parametrize("network,at_least", [("s3d", 50), ("r50", 20)])
+def test_conv_adjoint_identities_every_layer_full_size(network, at_least):
+    """S3D (BASELINE configs 2-4) and ResNet2d3d-50 (config 5: Cin/Cout up to 2048, the (1,3,3)/2
+    zero-upsampled data gradient, the five-launch (5,7,7) stem) at B=32."""
     from coclr_amd import ops, engine
     run = engine.Run(torch.device("cuda"), save=False)
-    geoms = _s3d_geometries()
-    assert len(geoms) >= 50
+    geoms = _geometries(network)
+    assert len(geoms) >= at_least
     g0 = torch.Generator(device="cuda").manual_seed(7)
     worst = 0.0
-    for (cin, cout, idim, k, s, p) in geoms:
-        g = ops.ConvGeom(B, cin, cout, idim, k, s, p)
+    for (cin, cout, idim, k, s, p, odim) in geoms:
+        g = ops.ConvGeom(B, cin, cout, idim, k, s, p, odim=odim)
         x = torch.randn(B, cin, *idim, device="cuda", generator=g0)
         w = torch.randn(cout, cin, *k, device="cuda", generator=g0) * 0.05
         dy = torch.randn(B, cout, *g.odim, device="cuda", generator=g0)
@@ -66,15 +72,19 @@ def test_conv_adjoint_identities_every_s3d_layer_full_size():
         ops.conv_fwd(g, x, run.pack(w, False), y)
         ref = _dot(y, dy)
         scale = float(y.double().norm() * dy.double().norm()) + 1e-30
-        # data gradient (phase-decomposed when the engine would use that form)
-        dx = torch.full_like(x, float("nan"))
-        phases = g.dgrad_phases()
-        if phases is not None:
-            for pg, k0, nk, step in phases:
-                ops.conv_fwd(pg, dy, run.pack(w, True, taps=nk, tap_base=k0, tap_step=step), dx)
-        else:
-            ops.conv_fwd(g.dgrad(), dy, run.pack(w, True), dx)
-        e_d = abs(_dot(x, dx) - ref) / scale
+        # data gradient (phase-decomposed when the engine would use that form); the network input
+        # never needs one (and the temporal slices of r50's stem have negative padding)
+        e_d = 0.0
+        dx = None
+        if cin != 3:
+            dx = torch.full_like(x, float("nan"))
+            phases = g.dgrad_phases()
+            if phases is not None:
+                for pg, k0, nk, step in phases:
+                    ops.conv_fwd(pg, dy, run.pack(w, True, taps=nk, tap_base=k0, tap_step=step), dx)
+            else:
+                ops.conv_fwd(g.dgrad(), dy, run.pack(w, True), dx)
+            e_d = abs(_dot(x, dx) - ref) / scale
         # weight gradient (direct form, and the form the engine's geometry selects when it differs:
         # Winograd F(2,3) for the wide (3,1,1) layers)
         dw = torch.empty_like(w)
@@ -82,19 +92,30 @@ def test_conv_adjoint_identities_every_s3d_layer_full_size():
         kk = k[0] * k[1] * k[2]
         ops.conv_wgrad(g, x, dy, dw, ws, cin * kk, kk, 0)
         e_w = abs(_dot(w, dw) - ref) / scale
-        ge = ops.conv_geom(B, cin, cout, idim, k, s, p)
+        ge = ops.conv_geom(B, cin, cout, idim, k, s, p) if min(p) >= 0 else g
         if ge.algo != g.algo:
+            # the forward and data gradient in the selected (Winograd) form too
+            y2 = torch.empty_like(y)
+            ops.conv_fwd(ge, x, run.pack(w, False, algo=ge.algo), y2)
+            e_w = max(e_w, float((y2 - y).abs().max() / y.abs().max()) * 1e-2)         # elementwise 1e-3
+            dg = ge.dgrad()
+            if dg.algo:
+                dx2 = torch.empty_like(x)
+                ops.conv_fwd(dg, dy, run.pack(w, True, algo=dg.algo), dx2)
+                e_d = max(e_d, abs(_dot(x, dx2) - ref) / scale)
+                del dx2
             dw2 = torch.empty_like(w)
             ws2 = torch.empty(ge.wgrad_workspace(), device="cuda")
             ops.conv_wgrad(ge, x, dy, dw2, ws2, cin * kk, kk, 0)
             e_w = max(e_w, abs(_dot(w, dw2) - ref) / scale)
             e_w = max(e_w, float((dw2 - dw).abs().max() / dw.abs().max()) * 1e-2)   # elementwise 1e-3
-            del dw2, ws2
+            del dw2, ws2, y2
         worst = max(worst, e_d, e_w)
         # fp32 products summed over up to 1e9 terms: 1e-5 of the Cauchy-Schwarz scale
-        assert e_d <= 1e-5 and e_w <= 1e-5, (cin, cout, idim, k, s, e_d, e_w)
+        assert e_d <= 1e-5 and e_w <= 1e-5, (cin, cout, idim, k, s, p, e_d, e_w)
         del x, w, dy, y, dx, dw, ws
-    print("worst adjoint mismatch (relative to |y||dy|): %.2e over %d geometries" % (worst, len(geoms)))
+    print("%s: worst adjoint mismatch (relative to |y||dy|): %.2e over %d geometries"
+          % (network, worst, len(geoms)))
 
 
 def test_conv_epilogue_statistics_full_size():

@@ -1,5 +1,7 @@
 """world_size 2 ON HARDWARE with a single MI355X: both ranks run on cuda:0 (real HIP kernels,
-real streams, the captured hipGraphs, DistributedDataParallel), collectives go over gloo.  RCCL itself
+real streams, the captured hipGraphs, DistributedDataParallel), collectives go over gloo (device
+all-gather / all-to-all payloads staged through the host underneath torch.distributed's API, so the
+product's own exchange code -- routed all-to-all (the default), all-gather, peer row pull -- is what runs).  RCCL itself
 refuses two ranks on one device, so this is not the fabric path -- it is the W > 1 HOST SEQUENCING
 executed with the product kernels instead of the ATen double, plus the peer row-pull exchange
 (`COCLR_SHUFFLE=pull`, csrc/nce.hip pull_rows_kernel) through real hipIpc mappings between two
@@ -30,14 +32,27 @@ def _worker(rank, world, kind, port, q):
         import model.pretrain as product
         from _cases import build_model, case_inputs, check_close, load_golden, loss_fn
 
-        # gloo moves no device tensors in all_gather: stage the (tiny) key / label gathers through
-        # the host for this test; broadcast and all_reduce of device tensors are native in gloo
-        def host_staged_all_gather(tensor):
-            t = tensor.contiguous().cpu()
-            out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
-            dist.all_gather_into_tensor(out, t)
-            return out.to(tensor.device)
-        impl.concat_all_gather = host_staged_all_gather
+        # gloo carries device tensors for broadcast / all_reduce only: all_gather_into_tensor and
+        # all_to_all_single of DEVICE tensors are staged through the host at the torch.distributed
+        # level, so the product's own concat_all_gather / _routed_shuffle / _encode_keys code runs
+        # unmodified (over RCCL these two calls are the native collectives)
+        gather_native, a2a_native = dist.all_gather_into_tensor, dist.all_to_all_single
+
+        def all_gather_into_tensor(out, tensor, *a, **kw):
+            if not tensor.is_cuda:
+                return gather_native(out, tensor, *a, **kw)
+            host = torch.empty(out.shape, dtype=out.dtype)
+            gather_native(host, tensor.contiguous().cpu(), *a, **kw)
+            out.copy_(host)
+
+        def all_to_all_single(out, tensor, output_split_sizes=None, input_split_sizes=None, *a, **kw):
+            if not tensor.is_cuda:
+                return a2a_native(out, tensor, output_split_sizes, input_split_sizes, *a, **kw)
+            host = torch.empty(out.shape, dtype=out.dtype)
+            a2a_native(host, tensor.contiguous().cpu(), output_split_sizes, input_split_sizes, *a, **kw)
+            out.copy_(host)
+        dist.all_gather_into_tensor = all_gather_into_tensor
+        dist.all_to_all_single = all_to_all_single
 
         name = "%s_s3d_small_world2" % kind
         gold = load_golden("%s_rank%d" % (name, rank))
@@ -87,6 +102,11 @@ def _worker(rank, world, kind, port, q):
 
         outs_pull, sd_pull = run("pull")
         outs_ag, sd_ag = run("allgather")
+        # the DEFAULT exchange (COCLR_SHUFFLE=routed: all_to_all_single of exactly the clips each
+        # rank encodes, pretrain.py:_routed_shuffle) with the real kernels: first step only
+        gold["steps"] = gold["steps"][:1]
+        outs_rt, _ = run("routed")
+        assert torch.equal(outs_rt[0], outs_ag[0]), "routed all-to-all and all-gather exchange disagree"
         # the two exchange schemes deliver the same clips: the first step is bit-identical; from the
         # second step on the runs differ by what two runs of ONE scheme differ by (the pooling
         # backward accumulates through LDS float atomics: gradients are reproducible to fp32
