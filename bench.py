@@ -19,8 +19,15 @@ timed region.
 Legs (all in the one JSON line):
   value                    the drop-in: `torch.optim.Adam` resolved to the single-launch subclass by the
                            model.pretrain shim, loss + accuracy through coclr_amd.loss (device scalars)
+  value_unmodified_caller  what main_nce.py gets WITHOUT editing a line of it: the shim's Adam (the script
+                           constructs `optim.Adam`), but the script's own nn.CrossEntropyLoss,
+                           utils.calc_topk_accuracy and the three `.item()` host syncs of
+                           main_nce.py:314-327 per iteration
+  value_split_stages       `value` with the backbone as one autograd node PER STAGE: the structure every
+                           rank runs at world > 1 (DDP's all-reduce starts while early stages are
+                           still in backward), i.e. the per-rank cost the scaling curve starts from
   value_caller_optimizer   the same step with torch's OWN Adam over the same 470 groups and
-                           nn.CrossEntropyLoss (what an unpatched caller would get)
+                           nn.CrossEntropyLoss (COCLR_PATCH_ADAM=0)
   roofline        dominant kernel (Conv_2c.conv1, spatial Winograd): MFMA FLOPs ACTUALLY ISSUED / time
                   / 157.3 TF, in-step (HIP events on the launch stream) and isolated; the
                   direct-convolution-equivalent figure is kept as `direct_equiv`
@@ -81,6 +88,17 @@ def synthetic_block(B, seq_len, img_dim, device, seed):
     std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1, 1)
     x = (x - mean) / std
     return x.view(B, 3, 2, seq_len, img_dim, img_dim).transpose(1, 2).contiguous()
+
+
+def caller_topk_accuracy(output, target, topk=(1,)):
+    """The launch script's accuracy helper (utils/utils.py:52-69), caller-side code in the reference's
+    own formulation: top-k over the whole logits row, transpose, compare, slice sums."""
+    maxk = max(topk)
+    batch_size = target.size(0)
+    _, pred = output.topk(maxk, 1, True, True)
+    pred = pred.t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0) * (1 / batch_size) for k in topk]
 
 
 class KernelTimer:
@@ -262,11 +280,19 @@ def main():
 
     acc = {}
 
+    torch_ce = nn.CrossEntropyLoss().cuda(local_rank) if not dry else nn.CrossEntropyLoss()
+    meters = {}
+
     def step(i, native=True):
         blocks = pool[i % 2]
         if args.model == "infonce":
             out, tgt = ddp(blocks[0])
-            if native:
+            if native == "unmodified":
+                # main_nce.py:313-327 verbatim: criterion, accuracy helper, three host reads
+                loss = torch_ce(out, tgt)
+                top1, top5 = caller_topk_accuracy(out, tgt, (1, 5))
+                meters["top1"], meters["top5"], meters["loss"] = top1.item(), top5.item(), loss.item()
+            elif native:
                 loss = criterion(out, tgt)
                 acc["top1"], acc["top5"] = L.calc_topk_accuracy(out, tgt, (1, 5))
             else:
@@ -320,6 +346,34 @@ def main():
                   "what": "torch.optim.Adam (torch's implementation) over %d single-tensor groups + "
                           "nn.functional.cross_entropy, everything else identical" % len(groups)}
         cur = opt
+
+    # ---- the unmodified script's iteration, and the world>1 autograd structure --------------------------
+    unmodified = split = None
+    if not args.no_extra_legs and args.model == "infonce":
+        for i in range(2):
+            step(i, native="unmodified")
+        n3 = max(3, min(args.steps, 10))
+        dt3, t_host3, _, _ = timed_run(n3, "unmodified")
+        unmodified = {"value": round(B * world * n3 / dt3, 2), "ms_per_step": round(dt3 / n3 * 1e3, 3),
+                      "steps": n3,
+                      "what": "main_nce.py:307-331 as written: the shim-resolved torch.optim.Adam, "
+                              "nn.CrossEntropyLoss, utils.calc_topk_accuracy (ATen top-k over the "
+                              "logits), top1.item() / top5.item() / loss.item() every iteration"}
+        if args.net in ("s3d", "s3dg") and world == 1:
+            from coclr_amd.backbone import s3dg as _s3dg
+            saved_mode = _s3dg._SPLIT_MODE
+            _s3dg._SPLIT_MODE = "1"
+            try:
+                for i in range(2):
+                    step(i)
+                dt4, _, _, _ = timed_run(n3, True)
+            finally:
+                _s3dg._SPLIT_MODE = saved_mode
+            split = {"value": round(B * world * n3 / dt4, 2), "ms_per_step": round(dt4 / n3 * 1e3, 3),
+                     "steps": n3,
+                     "what": "`value` with one autograd node per backbone stage (COCLR_SPLIT_STAGES=1), "
+                             "the structure used at world > 1"}
+            step(0)
 
     # ---- host floor: the same step on 4 clips per GPU, where the GPU is never the bottleneck -----------
     host_floor = None
@@ -459,6 +513,10 @@ def main():
                          "host_floor = the same step at 4 clips/GPU, where only the host paces it",
             "abi_calls_per_step": round(calls_per_step, 1),
         }
+        if unmodified is not None:
+            rec["value_unmodified_caller"] = unmodified
+        if split is not None:
+            rec["value_split_stages"] = split
         if caller is not None:
             rec["value_caller_optimizer"] = caller
         if world == 1 and not args.no_cpu_baseline:

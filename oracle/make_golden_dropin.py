@@ -31,7 +31,7 @@ CASES = {
         "--net", "s3d", "--model", "coclr", "--topk", "2", "--moco-k", "8", "--batch_size", "4",
         "--seq_len", "8", "--img_dim", "64", "--epochs", "1", "--workers", "0", "--print_freq", "1",
         "--seed", "0", "--multiprocessing-distributed", "--world-size", "1", "--rank", "0",
-        "--dist-backend", "gloo"],
+        "--dist-backend", "gloo", "--pretrain", "{tmp}/rgb.pth.tar", "{tmp}/flow.pth.tar"],
         dict(n=20, seq_len=8, img_dim=64, two_stream=True, seed=78)),
 }
 KEEP = ("queue", "queue_ptr", "queue_second", "queue_vname", "queue_label",
@@ -46,7 +46,10 @@ def main():
     for name, (script, argv, spec) in CASES.items():
         ds = H.SyntheticClips(**spec)
         with tempfile.TemporaryDirectory() as tmp:
-            rec = H.run_script(script, argv, ds, use_reference_model=True, cpu=True, workdir=tmp)
+            if script == "main_coclr":
+                H.write_pretrained_pair(tmp, use_reference_model=True)
+            rec = H.run_script(script, [a.format(tmp=tmp) for a in argv], ds, use_reference_model=True,
+                               cpu=True, workdir=tmp)
         sd = rec["checkpoint"]["state_dict"]
         opt = rec["checkpoint"]["optimizer"]
         gold = {

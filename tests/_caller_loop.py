@@ -91,9 +91,31 @@ def run_nce(product, dataset, *, net="s3d", moco_k=32, batch_size=4, seq_len=16,
     return rec
 
 
+def _load_pretrained_pair(model_without_ddp, pretrain):
+    """main_coclr.py:251-300: the FIRST checkpoint's encoder_q initialises encoder_q AND encoder_k, the
+    SECOND checkpoint's encoder_q becomes the frozen sampler; queues are never loaded; then
+    utils.neq_load_customized: update the model's own state dict and load it back."""
+    second = torch.load(pretrain[1], map_location=torch.device('cpu'), weights_only=False)['state_dict']
+    second = {k.replace('encoder_q.', 'sampler.'): v for k, v in second.items() if 'encoder_q.' in k}
+    second = {k: v for k, v in second.items() if 'queue' not in k}
+    first = torch.load(pretrain[0], map_location=torch.device('cpu'), weights_only=False)['state_dict']
+    first = {k: v for k, v in first.items() if 'queue' not in k}
+    both = {}
+    for k, v in first.items():
+        if 'encoder_q.' in k:
+            both[k] = v
+            both[k.replace('encoder_q.', 'encoder_k.')] = v
+    state_dict = {**both, **second}
+    state_dict.pop('queue_label', None)
+    model_dict = model_without_ddp.state_dict()
+    model_dict.update({k: v for k, v in state_dict.items() if k in model_dict})
+    model_without_ddp.load_state_dict(model_dict)
+
+
 def run_coclr(product, dataset, *, net="s3d", moco_k=8, topk=2, batch_size=4, seq_len=8, img_dim=64,
-              seed=0, lr=1e-3, wd=1e-5, gpu=None, calc_topk_accuracy=None, calc_mask_accuracy=None):
-    """main_coclr.py, one epoch, --pretrain random random."""
+              seed=0, lr=1e-3, wd=1e-5, gpu=None, calc_topk_accuracy=None, calc_mask_accuracy=None,
+              pretrain=None):
+    """main_coclr.py, one epoch, --pretrain <rgb checkpoint> <flow checkpoint>."""
     torch.manual_seed(seed)
     np.random.seed(seed)
     random.seed(seed)
@@ -102,6 +124,8 @@ def run_coclr(product, dataset, *, net="s3d", moco_k=8, topk=2, batch_size=4, se
                                          dict(device_ids=[gpu]) if gpu is not None else {})
     rec = {"outputs": [], "targets": [], "losses": []}
     batches = _loader(dataset, batch_size, gpu is not None)
+    if pretrain is not None:
+        _load_pretrained_pair(model.module, pretrain)
     np.random.seed(0)
     random.seed(0)
     for g in optimizer.param_groups:

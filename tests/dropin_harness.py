@@ -180,6 +180,52 @@ class SyntheticClips(torch.utils.data.Dataset):
         return self.frames[0][i], self.label[i]
 
 
+def write_pretrained(path, infonce_model, seed):
+    """A checkpoint in the format main_nce.py saves (main_nce.py:281-288) whose encoders are WELL
+    CONDITIONED: conv weights He-normal from a seeded generator (in state-dict order), BatchNorm at
+    identity.  At the scripts' own `normal_(0, 0.01)` initialisation a frozen eval-mode sampler maps
+    every clip to (almost) the same feature, so CoCLR's top-k mining (model/pretrain.py:405-410)
+    decides between similarities that differ by float round-off; `main_coclr.py --pretrain A B`
+    loads these instead, as its README recipe does with InfoNCE checkpoints.  Built from parameter
+    names and shapes only, so the reference's model and the product's produce the same file."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in infonce_model.state_dict().items():
+        v = v.detach().cpu().clone()
+        if v.dim() == 5 and k.endswith("weight"):
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3] * v.shape[4]
+            v = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+        sd[k] = v
+    # S3D registers every stage twice (Conv_1a.* and block1.0.*, backbone/s3dg.py:145-150): keys that
+    # alias one tensor must carry the same values
+    live = infonce_model.state_dict()
+    by_ptr = {}
+    for k, v in live.items():
+        if v.dim() == 5:
+            by_ptr.setdefault(v.data_ptr(), []).append(k)
+    for keys in by_ptr.values():
+        for k in keys[1:]:
+            sd[k] = sd[keys[0]]
+    torch.save({"epoch": 0, "state_dict": sd, "best_acc": 0, "iteration": 1}, path)
+    return sd
+
+
+PRETRAIN_SEEDS = {"rgb": 501, "flow": 502}
+
+
+def write_pretrained_pair(directory, use_reference_model, product=None):
+    """rgb.pth.tar / flow.pth.tar for `main_coclr.py --pretrain`, from the reference's InfoNCE (fixture
+    generation) or the product's (tests): same names, shapes and values either way."""
+    if product is None:
+        with script_environment(use_reference_model, cpu=True):
+            import model.pretrain as product_mod
+            model = product_mod.InfoNCE("s3d", 128, 8, 0.999, 0.07)
+    else:
+        model = product.InfoNCE("s3d", 128, 8, 0.999, 0.07)
+    for tag, seed in PRETRAIN_SEEDS.items():
+        write_pretrained(os.path.join(directory, tag + ".pth.tar"), model, seed)
+
+
 def run_script(name, argv, dataset, use_reference_model, cpu, workdir, port=29641, before_train=None):
     """main_worker(gpu=0, ngpus_per_node=1, parse_args()) of the unmodified script.  Returns the
     observation record {"outputs", "targets", "losses", "checkpoint"}."""

@@ -65,8 +65,11 @@ def test_unmodified_script_runs_on_shadow_modules(fake, tmp_path, name, capsys):
         seen["adam_cls"] = torch.optim.Adam
         seen["native"] = native.Adam
         seen["bucket_view"] = model.gradient_as_bucket_view
-    rec = H.run_script(gold["script"], gold["argv"], ds, use_reference_model=False, cpu=True,
-                       workdir=str(tmp_path), port=29643, before_train=before_train)
+    if gold["script"] == "main_coclr":
+        H.write_pretrained_pair(str(tmp_path), use_reference_model=False)
+    rec = H.run_script(gold["script"], [a.format(tmp=str(tmp_path)) for a in gold["argv"]], ds,
+                       use_reference_model=False, cpu=True, workdir=str(tmp_path), port=29643,
+                       before_train=before_train)
     assert seen["is_product"], "the script did not pick up the shadow model package"
     assert seen["adam_cls"] is seen["native"], "torch.optim.Adam was not resolved to the native subclass"
     assert seen["bucket_view"] is True
@@ -84,8 +87,10 @@ def test_restated_caller_loop_is_the_script(fake, tmp_path, name):
     import _caller_loop
     gold = load_golden(name)
     ds = H.SyntheticClips(**gold["dataset"])
-    rec = H.run_script(gold["script"], gold["argv"], ds, use_reference_model=False, cpu=True,
-                       workdir=str(tmp_path), port=29644)
+    if gold["script"] == "main_coclr":
+        H.write_pretrained_pair(str(tmp_path), use_reference_model=False)
+    rec = H.run_script(gold["script"], [a.format(tmp=str(tmp_path)) for a in gold["argv"]], ds,
+                       use_reference_model=False, cpu=True, workdir=str(tmp_path), port=29644)
     from oracle import coclr_oracle as orc
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29645", rank=0, world_size=1)
@@ -95,7 +100,9 @@ def test_restated_caller_loop_is_the_script(fake, tmp_path, name):
                 mine = _caller_loop.run_nce(product, ds, calc_topk_accuracy=orc.calc_topk_accuracy)
             else:
                 mine = _caller_loop.run_coclr(product, ds, calc_topk_accuracy=orc.calc_topk_accuracy,
-                                              calc_mask_accuracy=orc.calc_mask_accuracy)
+                                              calc_mask_accuracy=orc.calc_mask_accuracy,
+                                              pretrain=(str(tmp_path / "rgb.pth.tar"),
+                                                        str(tmp_path / "flow.pth.tar")))
     finally:
         dist.destroy_process_group()
     assert len(mine["outputs"]) == len(rec["outputs"])

@@ -24,7 +24,7 @@ def _ensure_pg():
 
 
 @pytest.mark.parametrize("name", ["dropin_main_nce", "dropin_main_coclr"])
-def test_caller_sequence_on_gpu_matches_reference_scripts(name):
+def test_caller_sequence_on_gpu_matches_reference_scripts(name, tmp_path):
     import dropin_harness as H
     import _caller_loop
     import model.pretrain as product
@@ -35,8 +35,11 @@ def test_caller_sequence_on_gpu_matches_reference_scripts(name):
     ds = H.SyntheticClips(**gold["dataset"])
     two_stream = gold["script"] == "main_coclr"
     if two_stream:
+        # main_coclr.py --pretrain <rgb> <flow>: well-conditioned encoders (dropin_harness.write_pretrained)
+        H.write_pretrained_pair(str(tmp_path), use_reference_model=False, product=product)
         rec = _caller_loop.run_coclr(product, ds, gpu=0, calc_topk_accuracy=orc.calc_topk_accuracy,
-                                     calc_mask_accuracy=orc.calc_mask_accuracy)
+                                     calc_mask_accuracy=orc.calc_mask_accuracy,
+                                     pretrain=(str(tmp_path / "rgb.pth.tar"), str(tmp_path / "flow.pth.tar")))
     else:
         rec = _caller_loop.run_nce(product, ds, gpu=0, calc_topk_accuracy=orc.calc_topk_accuracy)
     assert isinstance(rec["optimizer"], native.Adam) and rec["optimizer"]._plan is not None
