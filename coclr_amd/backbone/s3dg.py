@@ -159,6 +159,7 @@ class SepInception(_Emitter):
     def _emit(self, run, x):
         N, _, T, H, W = x.shape
         odim = (T, H, W)          # every branch preserves the extent
+        run.lanes_on = engine.lanes_for(run, odim)
         block = run.empty(N, self.out_channels, *odim)
         dst, c0 = [], 0
         for width in self._widths:

@@ -32,10 +32,29 @@ WGRAD_STREAM = os.environ.get("COCLR_WGRAD_STREAM", "1") != "0"
 # Inception branches on their own streams: correct (GPU tier passes with it on) but SLOWER on
 # MI355X -- 47.3 vs 43.3 ms/step: ~160 fork/join points per step cost more in cross-queue
 # event latency than the overlap of the small branch kernels wins.  Off unless asked for.
-LANES = os.environ.get("COCLR_LANES", "0") == "1"
+# COCLR_LANES: "1" everywhere; "small" only in blocks on maps of 8x8 and below (stages 4 and 5, whose
+# 10-40 us kernels leave most of the chip idle); "graph" only while the pass is being captured into a
+# hipGraph (the forks become graph branches, no host-issued cross-queue events); "small+graph" both.
+LANES_MODE = os.environ.get("COCLR_LANES", "0")
+LANES = LANES_MODE != "0"
+
+
+def lanes_for(run, dims):
+    """Should the inception block on a map of extent `dims` run its branches on lane streams?"""
+    if not LANES or run.device.type != "cuda":
+        return False
+    if LANES_MODE == "1":
+        return True
+    ok = True
+    if "small" in LANES_MODE:
+        ok = ok and dims[1] <= 8
+    if "graph" in LANES_MODE:
+        ok = ok and torch.cuda.is_current_stream_capturing()
+    return ok
 _SIDE = {}
 _SIDE_PRIORITY = int(os.environ.get("COCLR_WGRAD_PRIORITY", "0"))
-_SIDE_WINDOW = 12     # weight-gradient closures per release window (Run.side_stream)
+# weight-gradient closures per release window (Run.side_stream); 0 = hold everything until join_side
+_SIDE_WINDOW = int(os.environ.get("COCLR_SIDE_WINDOW", "12"))
 _LANES = {}
 
 
@@ -45,20 +64,25 @@ class _Lane:
 
     def __enter__(self):
         run = self.run
-        if run.cur_lane is not None:
+        if run.cur_lane is not None or run._in_lane:
             raise RuntimeError("coclr_amd: lanes do not nest")
-        if LANES and run.device.type == "cuda":
+        run._in_lane = True
+        if run.lanes_on:
             st, parent = run._lane_stream(self.idx)
             st.wait_stream(parent)
             run._parent = parent
             run._open.append(st)
             self.ctx = torch.cuda.stream(st)
             self.ctx.__enter__()
-        run.cur_lane = self.idx
+            run.cur_lane = self.idx          # closures recorded inside replay on the lane's stream
+        else:
+            run.cur_lane = None
+        self.entered = True
         return self
 
     def __exit__(self, *exc):
         self.run.cur_lane = None
+        self.run._in_lane = False
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
         return False
@@ -185,6 +209,8 @@ class Run:
         # whose grad_fn owns that stage's run) -- GBs of activations parked behind gc's schedule.
         self.tape = []
         self.cur_lane = None
+        self.lanes_on = False  # set per inception block (lanes_for)
+        self._in_lane = False
         self._parent = None
         self._open = []
         self.grads = {}        # id(base tensor) -> grad tensor
@@ -272,7 +298,7 @@ class Run:
         started = {}
         while self.tape:
             fn, lane = self.tape.pop()
-            if lane is None or not (LANES and self.device.type == "cuda"):
+            if lane is None:
                 if started:
                     cur = torch.cuda.current_stream(self.device)
                     for st in started.values():
@@ -316,7 +342,7 @@ class Run:
         # references (one event query per window, so the host cost stays negligible while the
         # peak is activations + a few windows of dy instead of activations + ALL dy).
         self._side_calls += 1
-        if self._side_calls % _SIDE_WINDOW == 0 and self._side_keep:
+        if _SIDE_WINDOW and self._side_calls % _SIDE_WINDOW == 0 and self._side_keep:
             ev = torch.cuda.Event()
             ev.record(st)
             self._side_windows.append((ev, self._side_keep))
@@ -345,7 +371,14 @@ class Run:
             if len(_PACK_STORE) > 4096:
                 for k_ in [k_ for k_, v_ in _PACK_STORE.items() if v_[0]() is None]:
                     del _PACK_STORE[k_]
-        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        if self.device.type != "cuda":
+            stream = 0
+        elif self.cur_lane is not None and self._parent is not None:
+            # inside a lane: the buffers (and the batch re-layout that fills them) belong to the parent
+            # stream, which the lane stream waited for when it forked
+            stream = self._parent.cuda_stream
+        else:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
         key = (tag, n, stream, self.device)
         buf = store[1].get(key)
         if buf is None:
