@@ -808,8 +808,17 @@ conv_wgrad_stem_kernel(const Wgrad2Args a) {
 // dW[co][ci*ci_stride' ...] = sum_s part[s][e]; destination may be a tap slice of a
 // larger stencil (r50 stem): e = co*J + ci*taps + tap ->
 // dst[co*co_stride + ci*ci_stride + tap_base + tap].
+// Rows [end[i-1], end[i]) of the reduced matrix land in dst[i] (row index local to the segment): the
+// fused 1x1x1 heads of an inception block are ONE weight-gradient GEMM whose row blocks belong to
+// three parameters living at unrelated addresses (views of DistributedDataParallel's buckets).
+struct WgradDst {
+  float* p[4];
+  int end[4];
+  int n;
+};
+
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long CJ, int S, int J,
+wgrad_reduce_kernel(const float* __restrict__ part, WgradDst dst, long CJ, int S, int J,
                     int taps, long co_stride, long ci_stride, int tap_base, int accumulate) {
   // 64 consecutive elements x 4 split groups per block; 4 independent loads in flight per
   // thread, fixed summation order (deterministic)
@@ -832,10 +841,13 @@ wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long
     __syncthreads();
     if (ty == 0 && e < CJ) {
       const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-      const long co = e / J;
+      long co = e / J;
       const int j = (int)(e - co * J);
       const int ci = j / taps, tap = j - ci * taps;
-      float* d = dw + co * co_stride + ci * ci_stride + tap_base + tap;
+      int sg = 0;
+      while (sg < dst.n - 1 && co >= dst.end[sg]) ++sg;
+      if (sg) co -= dst.end[sg - 1];
+      float* d = dst.p[sg] + co * co_stride + ci * ci_stride + tap_base + tap;
       *d = accumulate ? *d + s : s;
     }
     __syncthreads();
@@ -1025,11 +1037,37 @@ extern "C" int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* e
   return 0;
 }
 
+extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x, const float* dy,
+                                        float* const* dw_list, const int32_t* row_end, int nseg,
+                                        float* workspace, int64_t w_co_stride,
+                                        int64_t w_ci_stride, int tap_base, int accumulate,
+                                        void* stream_);
+
 extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, const float* dy,
                                   float* dw, float* workspace, int64_t w_co_stride,
                                   int64_t w_ci_stride, int tap_base, int accumulate,
                                   void* stream_) {
+  float* one[1] = {dw};
+  const int32_t end[1] = {d ? d->Cout : 0};
+  return coclr_conv3d_wgrad_multi(d, x, dy, one, end, 1, workspace, w_co_stride, w_ci_stride,
+                                  tap_base, accumulate, stream_);
+}
+
+extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x, const float* dy,
+                                        float* const* dw_list, const int32_t* row_end, int nseg,
+                                        float* workspace, int64_t w_co_stride,
+                                        int64_t w_ci_stride, int tap_base, int accumulate,
+                                        void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (!d || !dw_list || !row_end || nseg < 1 || nseg > 4) return COCLR_EINVAL;
+  WgradDst dst;
+  dst.n = nseg;
+  for (int i = 0; i < 4; ++i) {
+    dst.p[i] = i < nseg ? dw_list[i] : nullptr;
+    dst.end[i] = i < nseg ? row_end[i] : 0;
+    if (i < nseg && (!dw_list[i] || row_end[i] <= (i ? row_end[i - 1] : 0))) return COCLR_EINVAL;
+  }
+  if (row_end[nseg - 1] != d->Cout) return COCLR_EINVAL;
   WPlan w;
   int rc = plan_wgrad(d, &w);
   if (rc) return rc;
@@ -1129,7 +1167,7 @@ extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, cons
   const long CJ = (long)d->Cout * J;
   int blocks = cdiv(CJ, 64);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, CJ,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dst, CJ,
                      S_used, J, taps, (long)w_co_stride, (long)w_ci_stride, tap_base, accumulate);
   COCLR_LAUNCH_CHECK();
   return 0;

@@ -201,10 +201,12 @@ maxpool3d_tiled_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
   }
 }
 
-// Backward: the G input-gradient volumes live in LDS; every output element scatters its
-// gradient with one LDS float atomic (order of the <= 27 addends per element is not
-// fixed: results are reproducible to fp32 round-off, not bitwise), then the tile is
-// written (or accumulated) to HBM with coalesced stores.
+// Backward: the G input-gradient volumes live in LDS; every output element adds its gradient to
+// the input element it selected.  Run-to-run DETERMINISTIC and atomic-free: outputs are visited in
+// ceil(k/s)^3 colour classes ((ot, oh, ow) mod ceil(k/s)); the windows of two outputs of one class
+// are disjoint, so within a class the read-modify-writes cannot collide, and the classes run in a
+// fixed order with a barrier in between -- every input element receives its <= 27 addends in the
+// same order every time.  Then the tile is written (or accumulated) to HBM with coalesced stores.
 __global__ void __launch_bounds__(256)
 maxpool3d_tiled_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, float* dx,
                            const PoolGeom g, long dy_nstride, long dx_nstride, int accumulate,
@@ -214,16 +216,28 @@ maxpool3d_tiled_bwd_kernel(const float* __restrict__ dy, const int* __restrict__
   const int pl0 = blockIdx.x * G;
   const int gcount = min(G, planes - pl0);
   for (int i = threadIdx.x; i < gcount * Si; i += 256) tile[i] = 0.f;
-  __syncthreads();
-  for (int gi = 0; gi < gcount; ++gi) {
-    const int pl = pl0 + gi;
-    const int n = pl / g.C, c = pl - n * g.C;
-    const float* dyp = dy + (long)n * dy_nstride + (long)c * So;
-    const int* ip = idx + (long)pl * So;
-    float* tp = tile + gi * Si;
-    const int rebase = (pl % tfold) * Si;
-    for (int o = threadIdx.x; o < So; o += 256) atomicAdd(&tp[ip[o] - rebase], dyp[o]);
-  }
+  const int Pt = (g.kt + g.st - 1) / g.st, Ph = (g.kh + g.sh - 1) / g.sh, Pw = (g.kw + g.sw - 1) / g.sw;
+  for (int ct = 0; ct < Pt; ++ct)
+    for (int ch = 0; ch < Ph; ++ch)
+      for (int cw = 0; cw < Pw; ++cw) {
+        __syncthreads();
+        const int nt = (g.To - ct + Pt - 1) / Pt, nh = (g.Ho - ch + Ph - 1) / Ph,
+                  nw = (g.Wo - cw + Pw - 1) / Pw;
+        if (nt <= 0 || nh <= 0 || nw <= 0) continue;       // uniform across the workgroup
+        const int csize = nt * nh * nw;
+        for (int q = threadIdx.x; q < gcount * csize; q += 256) {
+          const int gi = q / csize;
+          int m = q - gi * csize;
+          const int a = m / (nh * nw);
+          m -= a * nh * nw;
+          const int b = m / nw, cc = m - b * nw;
+          const int o = ((a * Pt + ct) * g.Ho + (b * Ph + ch)) * g.Wo + (cc * Pw + cw);
+          const int pl = pl0 + gi;
+          const int n = pl / g.C, c = pl - n * g.C;
+          const int i = idx[(long)pl * So + o] - (pl % tfold) * Si;
+          tile[gi * Si + i] += dy[(long)n * dy_nstride + (long)c * So + o];
+        }
+      }
   __syncthreads();
   for (int gi = 0; gi < gcount; ++gi) {
     const int pl = pl0 + gi;

@@ -58,6 +58,25 @@ _SIDE_WINDOW = int(os.environ.get("COCLR_SIDE_WINDOW", "12"))
 _LANES = {}
 
 
+# Parameter -> the view of DistributedDataParallel's gradient bucket that holds its gradient
+# (coclr_amd/parallel.py fills this from its communication hook).  A backward pass writes weight
+# gradients STRAIGHT into those views and hands autograd a fresh alias of them: DDP then finds the
+# gradient already in its bucket and skips its per-parameter copy (235 tiny launches per step on the
+# critical stream).  Self-healing: a stale slot (buckets rebuilt, wrapper re-created) is just memory
+# -- DDP's own alias check copies from it as from any other gradient -- and the hook refreshes it.
+_GRAD_SLOTS = {}      # id(param) -> (weakref(param), bucket view)
+
+
+def set_grad_slot(param, view):
+    if view is None:
+        _GRAD_SLOTS.pop(id(param), None)
+        return
+    _GRAD_SLOTS[id(param)] = (weakref.ref(param), view)
+    if len(_GRAD_SLOTS) > 8192:
+        for k_ in [k_ for k_, v_ in _GRAD_SLOTS.items() if v_[0]() is None]:
+            del _GRAD_SLOTS[k_]
+
+
 class _Lane:
     def __init__(self, run, idx):
         self.run, self.idx, self.ctx = run, idx, None
@@ -215,6 +234,7 @@ class Run:
         self._open = []
         self.grads = {}        # id(base tensor) -> grad tensor
         self.param_grads = {}  # id(param) -> grad tensor
+        self._slots_out = set()   # parameters whose bucket view has been handed out in this run
         self.no_grad_bases = set()
         self.out = None
         self.plan = None       # PackPlan of the module being run
@@ -258,6 +278,19 @@ class Run:
         if g is None:
             raise RuntimeError("coclr_amd: activation has no gradient (unused output?)")
         return g if val.whole else g[:, val.c0:val.c0 + val.C]
+
+    def grad_out(self, p):
+        """Tensor to write d(loss)/d(p) into: a fresh alias of p's bucket view when DDP has one and the
+        caller's `.grad` is unset (zero_grad(set_to_none=True), torch's default: otherwise autograd
+        would ADD this tensor to a `.grad` that aliases it), else new memory."""
+        slot = _GRAD_SLOTS.get(id(p)) if _GRAD_SLOTS else None
+        if slot is not None and slot[0]() is p and p.grad is None and id(p) not in self.param_grads \
+                and id(p) not in self._slots_out:
+            v = slot[1]
+            if v.device == p.device and v.shape == p.shape and v.dtype == p.dtype:
+                self._slots_out.add(id(p))
+                return v.view_as(v)          # new tensor object: autograd adopts it without a copy
+        return torch.empty_like(p)
 
     def add_param_grad(self, p, g):
         old = self.param_grads.get(id(p))
@@ -561,7 +594,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
         def backward(run):
             dz = run.grad_of(out)
             dy = torch.empty_like(y)
-            dgb = run.empty(2, Cout)
+            dgb = (run.grad_out(bn.weight), run.grad_out(bn.bias))
             sums = run.empty(ops.bn_backward_workspace(N, Cout), dtype=torch.float64)
             dres = None
             dres_acc = False
@@ -575,7 +608,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                 run.add_param_grad(bn.bias, dgb[1])
             if w.requires_grad:
                 with torch.cuda.stream(run.side_stream(dy, xv)):
-                    dw = torch.empty_like(w)
+                    dw = run.grad_out(w)
                     kk = w.shape[2] * w.shape[3] * w.shape[4]
                     for t, g in enumerate(geoms):
                         ws = run.empty(g.wgrad_workspace())
@@ -665,7 +698,7 @@ def pointwise_group(run, x, units):
         def backward(run):
             dy = torch.empty_like(y)
             for (conv, bn, _), out, (c0, C_, mean, invstd, scale, shift) in zip(units, outs, saved):
-                dgb = run.empty(2, C_)
+                dgb = (run.grad_out(bn.weight), run.grad_out(bn.bias))
                 sums = run.empty(ops.bn_backward_workspace(N, C_), dtype=torch.float64)
                 ops.bn_act_backward(run.grad_of(out), y[:, c0:c0 + C_], None, scale, shift, mean,
                                     invstd, sums, dy[:, c0:c0 + C_], None, dgb[0], dgb[1], True,
@@ -676,14 +709,18 @@ def pointwise_group(run, x, units):
                     run.add_param_grad(bn.bias, dgb[1])
             if any(w.requires_grad for w in weights):
                 with torch.cuda.stream(run.side_stream(dy, xv)):
-                    dw = run.empty(Ccat, Cin, 1, 1, 1)
+                    # one GEMM, delivered to each head's own gradient tensor
                     ws = run.empty(geom.wgrad_workspace())
-                    ops.conv_wgrad(geom, xv, dy, dw, ws, Cin, 1, 0)
-                c0 = 0
-                for w in weights:
+                    if len(weights) <= 4:
+                        dws = [run.grad_out(w) for w in weights]
+                        ops.conv_wgrad(geom, xv, dy, dws, ws, Cin, 1, 0)
+                    else:
+                        dw = run.empty(Ccat, Cin, 1, 1, 1)
+                        ops.conv_wgrad(geom, xv, dy, dw, ws, Cin, 1, 0)
+                        dws = list(torch.split(dw, widths))
+                for w, dw in zip(weights, dws):
                     if w.requires_grad:
-                        run.add_param_grad(w, dw[c0:c0 + w.shape[0]])
-                    c0 += w.shape[0]
+                        run.add_param_grad(w, dw)
             if x_needs:
                 dx, acc = run.grad_target(x)
                 ops.conv_fwd(geom.dgrad(), dy, run.pack_concat(weights, True), dx, accumulate=acc)

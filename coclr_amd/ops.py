@@ -306,9 +306,22 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
 
 
 def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accumulate=False):
+    """dw: the gradient tensor, or a list of up to four tensors that take consecutive blocks of
+    output-channel rows (dw[i].shape[0] rows each, summing to geom.Cout)."""
     d = _desc(geom)
     d.x_nstride = _chk5(x, "x")
     d.y_nstride = _chk5(dy, "dy")
+    if isinstance(dw, (list, tuple)):
+        n = len(dw)
+        ptrs = (C.c_void_p * n)(*[_p(t) for t in dw])
+        ends, tot = [], 0
+        for t in dw:
+            tot += t.shape[0]
+            ends.append(tot)
+        _lib.check(_L().coclr_conv3d_wgrad_multi(
+            C.byref(d), _p(x), _p(dy), ptrs, (C.c_int32 * n)(*ends), n, _p(workspace), co_stride,
+            ci_stride, tap_base, int(accumulate), _stream()), "conv3d_wgrad_multi", geom)
+        return
     _lib.check(_L().coclr_conv3d_wgrad(
         C.byref(d), _p(x), _p(dy), _p(dw), _p(workspace), co_stride, ci_stride, tap_base,
         int(accumulate), _stream()), "conv3d_wgrad", geom)

@@ -9,6 +9,16 @@ tiny launches per step on the critical stream, ~1 ms of a 37 ms step on MI355X
 The flag only constrains callers that `detach_()` gradients; the launch scripts never touch
 `.grad` (they call `zero_grad()`, `backward()`, `step()`), so for modules of THIS package the shim
 makes True the default when the caller did not say otherwise.  `COCLR_PATCH_DDP=0` opts out.
+
+With the gradients living in the buckets, the remaining per-parameter work is DDP's copy INTO the
+bucket (`mul_out(bucket_view, grad, 1/world)`: 235 launches of ~3 us on the critical stream, even at
+world size 1).  The shim therefore also registers a communication hook on wrappers it defaulted
+(`COCLR_DDP_HOOK=0` opts out; nothing is registered when the caller chose the flag): the hook
+  * tells the engine where each parameter's gradient lives in the bucket (`engine.set_grad_slot`), so
+    the next backward writes weight gradients straight into the bucket views and DDP, finding them
+    there, copies nothing;
+  * averages per BUCKET: one `div_` over the flat buffer + one all-reduce (RCCL) -- bit-identical to
+    DDP's per-parameter pre-division for power-of-two world sizes, nothing at all at world size 1.
 """
 import inspect
 import os
@@ -32,6 +42,35 @@ _POS = _positional_index()
 _installed = [False]
 
 
+class _HookState:
+    def __init__(self, group):
+        self.group = group
+        self.seen = {}        # bucket index -> (buffer address, #parameters) already published
+
+
+def bucket_hook(state, bucket):
+    """DDP communication hook: publish the bucket's gradient views to the engine, then average the
+    flat buffer (what DDP's built-in path computes, per bucket instead of per parameter)."""
+    import torch.distributed as dist
+    from . import engine
+    buf = bucket.buffer()
+    sig = (buf.data_ptr(), buf.numel())
+    idx = bucket.index()
+    if state.seen.get(idx) != sig:
+        for p, g in zip(bucket.parameters(), bucket.gradients()):
+            engine.set_grad_slot(p, g)
+        state.seen[idx] = sig
+    group = state.group if state.group is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    if world == 1:
+        fut = torch.futures.Future()
+        fut.set_result(buf)
+        return fut
+    buf.div_(world)
+    return dist.all_reduce(buf, group=group, async_op=True).get_future().then(
+        lambda f: f.value()[0])
+
+
 def install(module_types):
     """Make `gradient_as_bucket_view=True` the default for DDP wrappers around `module_types`."""
     if os.environ.get("COCLR_PATCH_DDP", "1") == "0" or _installed[0]:
@@ -39,10 +78,13 @@ def install(module_types):
     orig = _DDP.__init__
 
     def __init__(self, module, *args, **kwargs):
-        if isinstance(module, module_types) and "gradient_as_bucket_view" not in kwargs and \
-                len(args) <= _POS:
+        ours = isinstance(module, module_types) and "gradient_as_bucket_view" not in kwargs and \
+            len(args) <= _POS
+        if ours:
             kwargs["gradient_as_bucket_view"] = True
-        return orig(self, module, *args, **kwargs)
+        orig(self, module, *args, **kwargs)
+        if ours and os.environ.get("COCLR_DDP_HOOK", "1") != "0":
+            self.register_comm_hook(_HookState(self.process_group), bucket_hook)
 
     __init__.__wrapped__ = orig
     __init__.__doc__ = orig.__doc__

@@ -120,6 +120,18 @@ int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, const float* dy
                        float* workspace, int64_t w_co_stride, int64_t w_ci_stride, int tap_base,
                        int accumulate, void* stream);
 
+/* The same gradient delivered to up to four destinations: output-channel rows
+ * [row_end[i-1], row_end[i]) go to dw_list[i] (row index local to the destination;
+ * row_end[nseg-1] == d->Cout).  For convolutions that stand for several parameters at once --
+ * the three 1x1x1 heads of an inception block run as one convolution over concatenated output
+ * channels (backbone/s3dg.py:97-104,119-123) -- whose gradients live at unrelated addresses
+ * (views of DistributedDataParallel's buckets, main_nce.py:172).  dw_list / row_end are HOST
+ * arrays read during the call. */
+int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x, const float* dy,
+                             float* const* dw_list, const int32_t* row_end, int nseg,
+                             float* workspace, int64_t w_co_stride, int64_t w_ci_stride,
+                             int tap_base, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* BatchNorm3d + ReLU (+ residual)  (backbone/s3dg.py:16-17,26-27,46-48,     */
 /*                                   60-64; backbone/resnet_2d3d.py:54-83)   */

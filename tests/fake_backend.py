@@ -131,13 +131,17 @@ def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accum
     with torch.enable_grad():
         out = _conv_raw(geom, _virtual_input(geom, x.detach(), None), w0)
         out.backward(dy.detach()[:geom.N])
-    dst = torch.as_strided(dw.reshape(-1), (geom.Cout, geom.Cin, geom.taps),
-                           (co_stride, ci_stride, 1), tap_base)
     g = w0.grad.reshape(geom.Cout, geom.Cin, geom.taps)
-    if accumulate:
-        dst.add_(g)
-    else:
-        dst.copy_(g)
+    r0 = 0
+    for t in (dw if isinstance(dw, (list, tuple)) else [dw]):
+        rows = t.shape[0] if isinstance(dw, (list, tuple)) else geom.Cout
+        dst = torch.as_strided(t, (rows, geom.Cin, geom.taps), (co_stride, ci_stride, 1),
+                               t.storage_offset() + tap_base)
+        if accumulate:
+            dst.add_(g[r0:r0 + rows])
+        else:
+            dst.copy_(g[r0:r0 + rows])
+        r0 += rows
 
 
 def bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt, momentum,

@@ -107,11 +107,10 @@ def _worker(rank, world, kind, port, q):
         gold["steps"] = gold["steps"][:1]
         outs_rt, _ = run("routed")
         assert torch.equal(outs_rt[0], outs_ag[0]), "routed all-to-all and all-gather exchange disagree"
-        # the two exchange schemes deliver the same clips: the first step is bit-identical; from the
-        # second step on the runs differ by what two runs of ONE scheme differ by (the pooling
-        # backward accumulates through LDS float atomics: gradients are reproducible to fp32
-        # round-off, not bitwise), and Adam at initialisation turns that round-off into +-lr weight changes under a 2-clip BatchNorm:
-        # the second step's logits agree to ~1e-3 between ANY two runs
+        # the two exchange schemes deliver the same clips: the first step is bit-identical; later steps
+        # are held to 5e-3 (the two runs see different allocator / graph-capture histories; nothing in
+        # the kernels is order-dependent any more, but Adam at initialisation would turn a single
+        # re-associated sum into +-lr weight changes under a 2-clip BatchNorm)
         assert torch.equal(outs_pull[0], outs_ag[0]), "row pull and all-gather exchange disagree"
         for a, b in zip(outs_pull[1:], outs_ag[1:]):
             check_close(a, b, 5e-3, "later steps, pull vs all-gather")

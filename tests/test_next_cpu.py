@@ -6,6 +6,8 @@ input staging, LinearClassifier, NN retrieval):
   * the product's HOST logic (coclr_amd/{loss,staging,optim}.py, model/classifier.py,
     eval/retrieval.py) on the ATen test double of tests/fake_backend.py against the same fixtures.
 The HIP kernels themselves are compared in tests/test_gpu_next.py."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -236,5 +238,72 @@ def test_ddp_default_for_this_model_only():
         assert DDP(m, gradient_as_bucket_view=False).gradient_as_bucket_view is False
         assert DDP(torch.nn.Linear(3, 3)).gradient_as_bucket_view is False
     finally:
+        if own:
+            dist.destroy_process_group()
+
+
+def test_gradients_are_written_into_ddp_buckets(fake, monkeypatch):
+    """DDP glue (coclr_amd/parallel.py + engine.grad_out): once the communication hook has published
+    the bucket views, a backward pass writes weight gradients straight into them -- `.grad` of the
+    backbone parameters aliases the bucket storage and DDP's per-parameter copy (`aten::mul`) is not
+    called for them -- and the parameters after four Adam steps are BIT-IDENTICAL to the run without
+    the hook (COCLR_DDP_HOOK=0: DDP's own per-parameter path)."""
+    import torch.distributed as dist
+    import model.pretrain as product
+    from coclr_amd import engine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29742")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        def run(hook):
+            monkeypatch.setenv("COCLR_DDP_HOOK", "1" if hook else "0")
+            engine._GRAD_SLOTS.clear()
+            torch.manual_seed(0)
+            model = product.InfoNCE('s3d', 128, 32, 0.999, 0.07)
+            ddp = torch.nn.parallel.DistributedDataParallel(model)
+            opt = torch.optim.Adam([{"params": p} for _, p in ddp.named_parameters()], lr=1e-3,
+                                   weight_decay=1e-5)
+            ddp.train()
+            aliased = []
+            for step in range(4):
+                g = torch.Generator().manual_seed(50 + step)
+                block = torch.randn(4, 2, 3, 8, 32, 32, generator=g)
+                torch.manual_seed(60 + step)
+                out, tgt = ddp(block)
+                loss = torch.nn.functional.cross_entropy(out, tgt)
+                opt.zero_grad()
+                loss.backward()
+                slots = engine._GRAD_SLOTS
+                n = 0
+                for p in model.encoder_q[0].parameters():
+                    s = slots.get(id(p))
+                    if s is not None and p.grad is not None and \
+                            p.grad.data_ptr() == s[1].data_ptr():
+                        n += 1
+                aliased.append(n)
+                opt.step()
+            return [p.detach().clone() for p in model.parameters()], aliased, model
+
+        ref, _, _ = run(False)
+        assert not engine._GRAD_SLOTS
+        got, aliased, model = run(True)
+        nparams = len(list(model.encoder_q[0].parameters()))
+        # step 0 publishes the first buckets, DDP rebuilds them once after it, step 1 publishes the
+        # rebuilt ones: from step 2 on every backbone gradient is produced in place
+        assert aliased[-1] == nparams and aliased[-2] == nparams, (aliased, nparams)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+        # a caller that keeps `.grad` (zero_grad(set_to_none=False)) must NOT get the in-place path
+        run_ = engine.Run(torch.device("cpu"), save=True)
+        p = next(model.encoder_q[0].parameters())
+        p.grad = torch.zeros_like(p)
+        assert run_.grad_out(p).data_ptr() != engine._GRAD_SLOTS[id(p)][1].data_ptr()
+        p.grad = None
+        assert run_.grad_out(p).data_ptr() == engine._GRAD_SLOTS[id(p)][1].data_ptr()
+        assert run_.grad_out(p).data_ptr() != engine._GRAD_SLOTS[id(p)][1].data_ptr()   # once per run
+    finally:
+        engine._GRAD_SLOTS.clear()
         if own:
             dist.destroy_process_group()
