@@ -361,6 +361,63 @@ maxpool333_kernel(const float* __restrict__ x, float* __restrict__ y, int* __res
   }
 }
 
+// Backward of the 3x3x3 / stride 1 / pad 1 pool, GATHER form: dy and the argmax indices of G whole
+// volumes are staged in LDS, thread i sums dy[o] over the <= 27 outputs o whose window holds input i
+// and whose argmax is i, in fixed (t, h, w) order: no atomics, run-to-run deterministic, every
+// thread busy (the scatter form has 27 colour classes of S/27 outputs each).
+__global__ void __launch_bounds__(256)
+maxpool333_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, float* dx,
+                      const PoolGeom g, long dy_nstride, long dx_nstride, int accumulate, int G,
+                      int planes, int lW, int lHW) {
+  extern __shared__ float lds[];
+  const int T = g.Ti, W = 1 << lW, HW = 1 << lHW, H = HW >> lW;
+  const int S = T << lHW;
+  float* dys = lds;                                  // [G][S]
+  int* ids = reinterpret_cast<int*>(lds + G * S);    // [G][S]
+  const int pl0 = blockIdx.x * G;
+  const int gcount = min(G, planes - pl0);
+  for (int gi = 0; gi < gcount; ++gi) {
+    const int pl = pl0 + gi;
+    const int n = pl / g.C, c = pl - n * g.C;
+    const float* dyp = dy + (long)n * dy_nstride + (long)c * S;
+    const int* ip = idx + (long)pl * S;
+    if ((dy_nstride & 3) == 0) {
+      for (int i = threadIdx.x; i < (S >> 2); i += 256) {
+        reinterpret_cast<float4*>(dys + gi * S)[i] = reinterpret_cast<const float4*>(dyp)[i];
+        reinterpret_cast<int4*>(ids + gi * S)[i] = reinterpret_cast<const int4*>(ip)[i];
+      }
+    } else {
+      for (int i = threadIdx.x; i < S; i += 256) { dys[gi * S + i] = dyp[i]; ids[gi * S + i] = ip[i]; }
+    }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < gcount * S; q += 256) {
+    const int gi = q / S, i = q - gi * S;
+    const int t = i >> lHW, h = (i >> lW) & (H - 1), w = i & (W - 1);
+    const float* dv = dys + gi * S;
+    const int* iv = ids + gi * S;
+    float s = 0.f;
+#pragma unroll
+    for (int dt = -1; dt <= 1; ++dt) {
+      if (t + dt < 0 || t + dt >= T) continue;
+#pragma unroll
+      for (int dh = -1; dh <= 1; ++dh) {
+        if (h + dh < 0 || h + dh >= H) continue;
+#pragma unroll
+        for (int dw = -1; dw <= 1; ++dw) {
+          if (w + dw < 0 || w + dw >= W) continue;
+          const int o = i + dt * HW + dh * W + dw;
+          if (iv[o] == i) s += dv[o];
+        }
+      }
+    }
+    const int pl = pl0 + gi;
+    const int n = pl / g.C, c = pl - n * g.C;
+    float* d = dx + (long)n * dx_nstride + (long)c * S + i;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
 constexpr int kTileFloats = 16384;   // 64 KiB of LDS per workgroup
 
 // planes per workgroup so that the tile is <= kTileFloats and there are enough workgroups
@@ -516,13 +573,35 @@ extern "C" int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, co
                                    int accumulate, void* stream) {
   if (!d || d->N <= 0 || d->C <= 0) return COCLR_EINVAL;
   const PoolGeom g0 = to_geom(d);
+  if (g0.kt == 3 && g0.kh == 3 && g0.kw == 3 && g0.st == 1 && g0.sh == 1 && g0.sw == 1 &&
+      g0.pt == 1 && g0.ph == 1 && g0.pw == 1) {
+    const int lW = ilog2_exact(g0.Wi), lHW = ilog2_exact(g0.Hi * g0.Wi);
+    const int S = g0.Ti * g0.Hi * g0.Wi;
+    // measured (B=32): 4x4x4 volumes 0.027 ms gather vs 0.055 colour classes; 8x8x8 0.084 vs 0.075;
+    // 16x16x16 0.327 vs 0.158 -- the 27-candidate scan is VALU-bound, it only pays on tiny volumes
+    if (lW >= 0 && lHW >= 0 && S <= 128) {
+      const int planes = g0.N * g0.C;
+      int G = 2048 / S;              // ~16 KiB of LDS (dy + indices): 8 workgroups per CU
+      if (G < 1) G = 1;
+      while (G > 1 && (planes + G - 1) / G < 2048) G >>= 1;
+      hipLaunchKernelGGL(maxpool333_bwd_kernel, dim3((planes + G - 1) / G), dim3(256),
+                         (size_t)G * S * 8, (hipStream_t)stream, dy, indices, dx, g0,
+                         (long)dy_nstride, (long)dx_nstride, accumulate, G, planes, lW, lHW);
+      COCLR_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   {
     const PoolGeom g = fold_time(g0);
     const int tfold = g.Ti == g0.Ti ? 1 : g0.Ti;
     const int Si = g.Ti * g.Hi * g.Wi;
     const int planes = g.N * g.C;
-    const int G = pick_group(planes, Si);
+    int G = pick_group(planes, Si);
     if (G > 0) {
+      // a colour class holds ~1/27 of a volume's outputs: keep enough volumes per workgroup for its
+      // 256 threads (1024 workgroups still fill the chip four deep)
+      G = 4096 / Si > 0 ? 4096 / Si : 1;
+      while (G > 1 && (planes + G - 1) / G < 1024) G >>= 1;
       static std::atomic<uint64_t> done{0};
       COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(maxpool3d_tiled_bwd_kernel),
                                      kTileFloats * 4, done));

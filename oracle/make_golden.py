@@ -25,6 +25,23 @@ import torch.nn.functional as F
 
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from _cases import condition_model  # noqa: E402  (shared with the tests that rebuild the model)
+
+# a wider sample of backbone tensors for the well-conditioned fixture (every one is held per tensor)
+GRAD_KEYS_S3D_WIDE = [
+    "encoder_q.0.Conv_1a.conv1.weight", "encoder_q.0.Conv_1a.conv2.weight",
+    "encoder_q.0.Conv_1a.bn1.weight", "encoder_q.0.Conv_1a.bn2.bias", "encoder_q.0.Conv_2b.conv.weight",
+    "encoder_q.0.Conv_2c.conv1.weight", "encoder_q.0.Conv_2c.conv2.weight",
+    "encoder_q.0.Conv_2c.bn2.weight", "encoder_q.0.Mixed_3b.branch0.0.conv.weight",
+    "encoder_q.0.Mixed_3b.branch1.1.conv1.weight", "encoder_q.0.Mixed_3b.branch2.1.conv1.weight",
+    "encoder_q.0.Mixed_3c.branch1.1.conv2.weight", "encoder_q.0.Mixed_3c.branch3.1.conv.weight",
+    "encoder_q.0.Mixed_4b.branch1.0.conv.weight", "encoder_q.0.Mixed_4c.branch2.1.conv2.weight",
+    "encoder_q.0.Mixed_4d.branch1.1.bn1.weight", "encoder_q.0.Mixed_4e.branch3.1.conv.weight",
+    "encoder_q.0.Mixed_4f.branch1.1.conv1.weight", "encoder_q.0.Mixed_5b.branch0.0.bn.bias",
+    "encoder_q.0.Mixed_5b.branch2.1.conv1.weight", "encoder_q.0.Mixed_5c.branch1.1.conv2.weight",
+    "encoder_q.0.Mixed_5c.branch1.1.bn2.weight", "encoder_q.2.weight", "encoder_q.2.bias",
+    "encoder_q.4.weight", "encoder_q.4.bias"]
 
 GRAD_KEYS_S3D = ["encoder_q.0.Conv_1a.conv1.weight", "encoder_q.0.Conv_1a.bn1.weight",
                  "encoder_q.0.Conv_1a.bn1.bias", "encoder_q.0.Conv_2c.conv2.weight",
@@ -97,6 +114,8 @@ def run_case(ref, cfg, rank=0, world=1):
     torch.manual_seed(cfg["model_seed"])
     if kind == "infonce":
         model = ref.InfoNCE(net, dim, K, cfg["m"], cfg["T"])
+        if cfg.get("condition"):
+            condition_model(model, cfg["condition"])
     elif kind == "ubernce":
         model = ref.UberNCE(net, dim, K, cfg["m"], cfg["T"])
     else:
@@ -119,6 +138,8 @@ def run_case(ref, cfg, rank=0, world=1):
 
     gold = {"cfg": cfg, "init_checksums": init_sums, "steps": []}
     grad_keys = GRAD_KEYS_R50 if net == "r50" else GRAD_KEYS_S3D
+    if cfg.get("condition"):
+        grad_keys = GRAD_KEYS_S3D_WIDE
     buf_keys = BUF_KEYS_R50 if net == "r50" else BUF_KEYS_S3D
     for step in range(cfg["steps"]):
         # every rank draws the whole global batch from the same seed and keeps its slice,
@@ -132,6 +153,19 @@ def run_case(ref, cfg, rank=0, world=1):
         if kind == "coclr":
             extra = torch.randint(0, cfg["n_sources"], (B * world,), generator=g)
         sl = slice(rank * B, (rank + 1) * B)
+        truth64 = None
+        if cfg.get("truth64") and step == 0:
+            # the REFERENCE model itself in float64 on the same weights, inputs and permutation: the
+            # yardstick for how reproducible its own fp32 gradients are
+            import copy
+            m64 = copy.deepcopy(model).double()
+            torch.manual_seed(cfg["perm_seed"] + step)
+            o64, t64 = m64(blocks[0][sl].double())
+            l64 = _loss(kind, o64, t64)
+            l64.backward()
+            n64 = dict(m64.named_parameters())
+            truth64 = ({k: _sample(n64[k].grad) for k in grad_keys}, l64.detach().clone())
+            del m64
         _PERMS.clear()
         torch.manual_seed(cfg["perm_seed"] + step)     # fixes randperm (pretrain.py:112)
         if kind == "infonce":
@@ -153,6 +187,8 @@ def run_case(ref, cfg, rank=0, world=1):
             "grad_checksums": _checksums({k: p.grad for k, p in named.items()
                                           if p.grad is not None}),
         }
+        if truth64 is not None:
+            rec["grads64"], rec["loss64"] = truth64
         opt.step()
         sd = model.state_dict()
         rec["buffers"] = {k: sd[k].detach().clone() for k in buf_keys}
@@ -189,6 +225,10 @@ CASES = {
                                          T=0.07, topk=5, reverse=True, clip=(3, 16, 64, 64),
                                          model_seed=4, input_seed=5, perm_seed=102, n_sources=6,
                                          steps=2),
+    # He-initialised, key encoder perturbed: loss ~ log K, gradients O(1); float64 truth recorded
+    "infonce_s3d_conditioned": dict(kind="infonce", network="s3d", B=4, K=32, dim=128, m=0.999, T=0.07,
+                                    clip=(3, 16, 128, 128), model_seed=0, input_seed=11, perm_seed=110,
+                                    steps=1, condition=dict(seed=9), truth64=True),
     "infonce_r50_small": dict(kind="infonce", network="r50", B=2, K=16, dim=128, m=0.999, T=0.07,
                               clip=(3, 8, 64, 64), model_seed=6, input_seed=7, perm_seed=103,
                               steps=2),

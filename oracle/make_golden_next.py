@@ -12,8 +12,8 @@ Reference files are imported UNMODIFIED from /root/reference.  Harness:
     train_one_epoch, restated here in the reference's own words;
   * utils/utils.py:67 calls `.view(-1)` on a non-contiguous slice, which PyTorch >= 1.7 rejects (the
     reference pins PyTorch 1.4): Tensor.view falls back to reshape for that call only;
-  * the retrieval block (eval/main_classifier.py:686-706) is inline script code: its fixture is
-    produced by the oracle's restatement (marked `pinned: False` in the file).
+  * the retrieval block (eval/main_classifier.py:686-706) is inline script code: it is cut out of
+    the file by line range and exec'd (`_reference_retrieval_block`; fixture marked `pinned: True`).
 """
 import ast
 import os
@@ -150,7 +150,7 @@ def main():
                os.path.join(OUT, "next_classifier.pt"))
     print("classifier:", logit_eval[0, :3].tolist())
 
-    # ---- NN retrieval (eval/main_classifier.py:686-706; restated, see module docstring) ---------
+    # ---- NN retrieval: the inline block eval/main_classifier.py:686-706, exec'd by line range -------
     sys.path.insert(0, os.path.join(HERE, ".."))
     from oracle import coclr_oracle as orc
     g = torch.Generator().manual_seed(31)
@@ -160,10 +160,34 @@ def main():
     tel = torch.randint(0, ncls, (nte,), generator=g)
     trf = centers[trl] * 0.3 + torch.randn(ntr, Cc, generator=g) + 2.0
     tef = centers[tel] * 0.3 + torch.randn(nte, Cc, generator=g) + 2.0
-    acc, sim = orc.nn_retrieval(tef, tel, trf, trl)
-    torch.save({"pinned": False, "train_feature": trf, "train_label": trl, "test_feature": tef,
+    acc, sim = _reference_retrieval_block(tef.clone(), tel, trf.clone(), trl)
+    acc_o, sim_o = orc.nn_retrieval(tef, tel, trf, trl)           # the restatement agrees
+    assert acc == acc_o and torch.equal(sim, sim_o)
+    torch.save({"pinned": True, "train_feature": trf, "train_label": trl, "test_feature": tef,
                 "test_label": tel, "acc": acc, "sim": sim}, os.path.join(OUT, "next_retrieval.pt"))
     print("retrieval:", acc)
+
+
+def _reference_retrieval_block(test_feature, test_label, train_feature, train_label):
+    """Run eval/main_classifier.py lines 686-706 (`ks = [1,5,10,20,50]` ... the k-NN loop's print) as
+    they lie in the file: the block is inline code of `test_retrieval`, so it is cut out by line range,
+    dedented and exec'd with the four tensors it reads in scope.  `torch.save(sim, ...)` inside it
+    writes into a scratch directory."""
+    import tempfile
+    import textwrap
+    import types
+    lines = open(os.path.join(REF, "eval", "main_classifier.py")).read().split("\n")
+    first = next(i for i, l in enumerate(lines) if l.strip() == "ks = [1,5,10,20,50]")
+    last = next(i for i in range(first, len(lines)) if "print('%dNN acc = %.4f' % (k, acc))" in lines[i])
+    assert (first + 1, last + 1) == (686, 706), (first + 1, last + 1)
+    src = textwrap.dedent("\n".join(lines[first:last + 1]))
+    with tempfile.TemporaryDirectory() as tmp:
+        env = {"torch": torch, "F": F, "os": os, "dirname": "",
+               "args": types.SimpleNamespace(test=os.path.join(tmp, "ckpt.pth.tar"), dataset="synthetic"),
+               "test_feature": test_feature, "train_feature": train_feature,
+               "test_label": test_label, "train_label": train_label}
+        exec(compile(src, os.path.join(REF, "eval", "main_classifier.py"), "exec"), env)
+    return env["NN_acc"], env["sim"]
 
 
 def _drop_self(mask):

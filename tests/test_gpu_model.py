@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from _cases import (assert_checksums, build_model, case_inputs, compare_state, compare_step,
-                    fp64_truth_grads, load_golden, loss_fn)
+                    fp64_truth_grads, load_golden, loss_fn, recorded_truth)
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,9 @@ def _replay(name, with_pg=False):
     for step, rec in enumerate(gold["steps"]):
         blocks, extra = case_inputs(cfg, step)
         before = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-        truth = fp64_truth_grads(cfg, rec, before, blocks, extra) if step == 0 else None
+        truth = None
+        if step == 0:
+            truth = recorded_truth(rec) or fp64_truth_grads(cfg, rec, before, blocks, extra)
         torch.manual_seed(cfg["perm_seed"] + step)
         if kind == "infonce":
             out, tgt = model(blocks[0].cuda())
@@ -68,7 +70,8 @@ def _replay(name, with_pg=False):
         after = model.state_dict()
         if step == 0:
             report = []
-            compare_step(rec, kind, out, tgt, loss, grads, truth=truth, report=report)
+            compare_step(rec, kind, out, tgt, loss, grads, truth=truth, report=report,
+                         strict="grads64" in rec)
             for k, e_got, e_ref in report:
                 print("%s grad %-50s err vs fp64 %.2e (reference fp32: %.2e)" % (name, k, e_got,
                                                                                e_ref))
@@ -104,6 +107,13 @@ def _replay(name, with_pg=False):
                                   "coclr_s3d_small_reverse_cold", "infonce_s3dg_small"])
 def test_small_cases_match_reference(name):
     _replay(name)
+
+
+def test_conditioned_case_every_gradient_tensor():
+    """De-saturated, He-initialised fixture (loss ~ 4.9 instead of ~5e-3) with float64 gradients
+    recorded from the REFERENCE model itself run in double: every one of the 26 sampled tensors --
+    stem to head -- is held, in the L2 norm, to 4x the reference's own fp32-vs-fp64 error."""
+    _replay("infonce_s3d_conditioned")
 
 
 def test_r50_matches_reference():

@@ -99,7 +99,8 @@ def _run_steps(name, rank=0, world=1, wrap_ddp=False):
 
 
 @pytest.mark.parametrize("name", ["infonce_s3d_small", "ubernce_s3d_small", "coclr_s3d_small",
-                                  "coclr_s3d_small_reverse_cold", "infonce_s3dg_small"])
+                                  "coclr_s3d_small_reverse_cold", "infonce_s3dg_small",
+                                  "infonce_s3d_conditioned"])
 def test_host_logic_matches_reference(fake, name):
     _run_steps(name)
 

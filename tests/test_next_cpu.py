@@ -99,7 +99,7 @@ def test_oracle_classifier_matches_reference():
 
 def test_oracle_retrieval_fixture_is_self_consistent():
     g = load_golden("next_retrieval")
-    assert g["pinned"] is False           # inline script code in the reference: restated, not imported
+    assert g["pinned"] is True            # eval/main_classifier.py:686-706 exec'd by line range (oracle/make_golden_next.py)
     acc, sim = orc.nn_retrieval(g["test_feature"], g["test_label"], g["train_feature"],
                                 g["train_label"])
     assert acc == g["acc"] and torch.equal(sim, g["sim"])

@@ -11,7 +11,7 @@ from _cases import (assert_checksums, build_model, case_inputs, check_close, che
                     sample)
 from oracle import coclr_oracle as orc
 
-SINGLE = ["infonce_s3d_small", "ubernce_s3d_small", "coclr_s3d_small",
+SINGLE = ["infonce_s3d_conditioned", "infonce_s3d_small", "ubernce_s3d_small", "coclr_s3d_small",
           "coclr_s3d_small_reverse_cold", "infonce_r50_small", "infonce_s3dg_small"]
 
 
