@@ -34,6 +34,7 @@
 //     accumulate, plus per-workgroup partial sums (sum, sum of squares) per
 //     output channel for train-mode BatchNorm, reduced with DPP row operations
 //     and written without atomics as [2][Cout][ntiles].
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -68,6 +69,7 @@ struct ConvArgs {
   float inv_plane1, inv_hw, inv_ww;
   int mtiles, ntiles, nchunks;
   int relu, accumulate;
+  int debug;             // timing ablations of the Winograd kernel (COCLR_WINO_DEBUG; wrong results)
 };
 
 // sum over each 16-lane row (result in every lane of the row)
@@ -736,7 +738,27 @@ __device__ __forceinline__ float agpr_read(float x) {
 
 constexpr int kWinoGrid = 256;    // persistent grid: one workgroup per CU
 
-template <int CC, int PCH>
+// LDS-DMA of 4 / 16 bytes per lane as plain __device__ functions: inside a template (the kernels' lambdas
+// are implicitly __host__ __device__ and re-checked at instantiation) the host pass, which has no
+// gfx950 features, rejects the 16-byte size.
+__device__ __forceinline__ void dma4_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voff,
+                                            unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_dst), 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voff,
+                                             unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
+}
+
+// X16: the window is staged with 16-BYTE LDS-DMA.  Its rows are widened to whole 16-byte granules of
+// the input row (global columns [2*ow0 - 4, 2*ow0 + 2*TW + 4): the patch of block b then starts at the
+// odd LDS column 3 + 2b), every lane of a DMA piece moves one granule, and a window of ~100 granules
+// takes TWO pieces per channel instead of six 4-byte ones.  The scattered 4-byte pieces are what the
+// kernel waits for (timing ablations: no window DMA -16 %, no weight DMA -4 %: a piece whose lanes
+// gather 18-float rows costs its wave ~5x a contiguous 1-KiB piece).  Needs Wi % 4 == 0 and 16-byte
+// aligned sample / channel strides; a.WW, a.plane1 are then the PADDED row / sample extents in floats,
+// a.plane the number of granules, a.inv_* the reciprocals in granule units.
+template <int CC, int PCH, bool X16 = false>
 __global__ void __launch_bounds__(256)
 conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   constexpr int TAPS = 16;
@@ -779,19 +801,21 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   const unsigned wvoff = (unsigned)lane * 16u;
 
   // tile-independent half of the window gather: the window coordinates (n, t, h, w) of the
-  // elements this lane fetches, packed one byte each, parked in LDS
+  // elements (X16: granules; w counts granules) this lane fetches, packed one byte each, parked in LDS
   {
-    const int hw = a.WH * WW;
+    const int rowlen = X16 ? WW >> 2 : WW;
+    const int hw = a.WH * rowlen;
+    const int p1 = X16 ? a.plane1 >> 2 : a.plane1;
 #pragma unroll
     for (int j = 0; j < PCH; ++j) {
       const int e = j * 64 + lane;
       unsigned crd = 0xffffffffu;
       if (e < plane) {
         const int wn_ = fdiv(e, a.inv_plane1);
-        int q = e - wn_ * a.plane1;
+        int q = e - wn_ * p1;
         const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
         const int wh = fdiv(q, a.inv_ww);
-        const int ww = q - wh * WW;
+        const int ww = q - wh * rowlen;
         crd = (unsigned)ww | ((unsigned)wh << 8) | ((unsigned)wt << 16) | ((unsigned)wn_ << 24);
       }
       wtab[j * 256 + tid] = crd;
@@ -807,7 +831,8 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
     pth = (p >> a.lTW) & ((1 << a.lTH) - 1);
     ptt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
     ptn = p >> (a.lTW + a.lTH + a.lTT);
-    lanebase = W_FLOATS + ptn * a.plane1 + (ptt * a.WH + pth * 2) * WW + ptw * 2 + half * planeS;
+    lanebase = W_FLOATS + ptn * a.plane1 + (ptt * a.WH + pth * 2) * WW + ptw * 2 + half * planeS +
+               (X16 ? 3 : 0);
   }
   // weights in LDS: [c][m][16 xi]; the four xi quads of row m sit rotated by m>>2, so the 16-byte
   // reads of 16 neighbouring rows fall on 16 different bank groups
@@ -830,13 +855,14 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
     n0 = r << a.lTN;
     ow0 = bw_ << a.lTW; oh0 = bh_ << a.lTH; ot0 = bt_ << a.lTT;      // ow0/oh0: BLOCK index
     cout0 = mt * BM;
-    const int vt0 = ot0, vh0 = oh0 * 2 - 1, vw0 = ow0 * 2 - 1;        // window origin
+    const int vt0 = ot0, vh0 = oh0 * 2 - 1, vw0 = ow0 * 2 - (X16 ? 4 : 1);   // window origin
 #pragma unroll
     for (int j = 0; j < PCH; ++j) {
       const unsigned c = wtab[j * 256 + tid];        // read back per tile: cheaper than 10 live registers
       const int ww = (int)(c & 255u), wh = (int)((c >> 8) & 255u), wt = (int)((c >> 16) & 255u),
                 wn_ = (int)(c >> 24);
-      const int iw = vw0 + ww, ih = vh0 + wh, it = vt0 + wt, n = n0 + wn_;
+      // X16: a granule starts on a multiple of four columns and Wi % 4 == 0: wholly inside or outside
+      const int iw = vw0 + (X16 ? 4 * ww : ww), ih = vh0 + wh, it = vt0 + wt, n = n0 + wn_;
       const bool ok = c != 0xffffffffu && n < a.N && it < a.Ti && (unsigned)ih < (unsigned)a.Hi &&
                       (unsigned)iw < (unsigned)a.Wi;
       const long off = (long)wn_ * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw;
@@ -849,7 +875,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   // DMA of one chunk into stage `sbase`.  Weights: the packed operand is [cin][cout][16 xi], so a
   // channel row of the 64-cout tile is 4 KiB = four 1 KiB pieces, copied verbatim.
   auto stage = [&](int cin0, float* sbase) {
-    {
+    if (!(a.debug & 2)) {
       // piece p = wave + 4k is quarter `wave` of channel row k: both offsets advance by constants
       unsigned soff = (unsigned)((((long)cin0 * a.CoutP + cout0) * 16 + wave * 256) * 4);
       const unsigned sstep = (unsigned)a.CoutP * 64u;
@@ -862,6 +888,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
       }
     }
     float* xs = sbase + W_FLOATS;
+    if (a.debug & 1) return;
 #pragma unroll
     for (int ci = 0; ci < CC / 4; ++ci) {
       const int c = ci * 4 + wave;
@@ -870,13 +897,20 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
         const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
 #pragma unroll
         for (int j = 0; j < PCH; ++j)
-          if (j * 64 < plane)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
-                                                     goff[j], soff, 0, 0);
+          if (j * 64 < plane) {
+            if (X16) dma16_to_lds(rx, xs + c * planeS + j * 256, goff[j], soff);
+            else dma4_to_lds(rx, xs + c * planeS + j * 64, goff[j], soff);
+          }
       } else {
 #pragma unroll
         for (int j = 0; j < PCH; ++j)
-          if (j * 64 < plane) xs[c * planeS + j * 64 + lane] = 0.f;
+          if (j * 64 < plane) {
+            if (X16)
+              *reinterpret_cast<float4*>(&xs[c * planeS + j * 256 + lane * 4]) =
+                  make_float4(0.f, 0.f, 0.f, 0.f);
+            else
+              xs[c * planeS + j * 64 + lane] = 0.f;
+          }
       }
     }
   };
@@ -944,8 +978,15 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const float* src = &cur[lanebase + rr * WW + 2 * q * planeS];
-          dv[2 * rr] = *reinterpret_cast<const f32x2*>(src);
-          dv[2 * rr + 1] = *reinterpret_cast<const f32x2*>(src + 2);
+          if (X16) {
+            // odd column: the middle pair is the aligned 8-byte read, the ends one ds_read2_b32
+            const f32x2 mid = *reinterpret_cast<const f32x2*>(src + 1);
+            dv[2 * rr].x = src[0]; dv[2 * rr].y = mid.x;
+            dv[2 * rr + 1].x = mid.y; dv[2 * rr + 1].y = src[3];
+          } else {
+            dv[2 * rr] = *reinterpret_cast<const f32x2*>(src);
+            dv[2 * rr + 1] = *reinterpret_cast<const f32x2*>(src + 2);
+          }
         }
       };
       auto transform = [&](const f32x2 (&dv)[8], float (&V)[16]) {
@@ -1071,16 +1112,17 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
       }
     };
     const bool fancy = a.bias || a.ep_scale || a.relu || a.accumulate;
-    if (fancy) emit(std::integral_constant<int, 2>{});
-    else if (want_stats) emit(std::integral_constant<int, 1>{});
+    if (a.debug & 4) {}
+    else if (fancy) emit(std::integral_constant<int, 2>{});
+    else if (want_stats && !(a.debug & 8)) emit(std::integral_constant<int, 1>{});
     else emit(std::integral_constant<int, 0>{});
     pend_ry = ry;
     pend_vo0 = yvoff;
     pend_vo1 = pvalid ? yvoff + row_bytes : OOB;
     pend_co0 = e_cout0 + wm * 32;
-    pending = true;
+    pending = !(a.debug & 4);
 
-    if (want_stats) {
+    if (want_stats && !(a.debug & 12)) {
       __syncthreads();
       // thread t: row t>>2, quarter t&3 of its 64 partials; the quarters meet through DPP
       const int row = tid >> 2, qtr = tid & 3;
@@ -1109,17 +1151,35 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   flush(std::integral_constant<int, 8>{});
 }
 
-template <int CC, int PCH>
+template <int CC, int PCH, bool X16 = false>
 int launch_wino_hw(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
-  if (p.plane > PCH * 64 || p.WW > 255 || p.WH > 255 || p.WT > 255 || p.lTN > 7) return COCLR_EINVAL;
+  if (p.WW > 255 || p.WH > 255 || p.WT > 255 || p.lTN > 7) return COCLR_EINVAL;
   a.mtiles = cdiv(a.Cout, 64);
-  a.planeS = cdiv(p.plane, 64) * 64;
+  if (X16) {
+    // rows widened to whole 16-byte granules: [2*ow0 - 4, 2*ow0 + 2*TW + 4)
+    const int wwp = 2 * (1 << p.lTW) + 8;
+    a.WW = wwp;
+    a.plane1 = p.WT * p.WH * wwp;
+    a.plane = (a.plane1 << p.lTN) / 4;                 // granules
+    if (a.plane > PCH * 64) return COCLR_EINVAL;
+    a.planeS = cdiv(a.plane, 64) * 256;
+    a.inv_plane1 = 1.0f / (float)(a.plane1 / 4);
+    a.inv_hw = 1.0f / (float)(p.WH * (wwp / 4));
+    a.inv_ww = 1.0f / (float)(wwp / 4);
+  } else {
+    if (p.plane > PCH * 64) return COCLR_EINVAL;
+    a.planeS = cdiv(p.plane, 64) * 64;
+  }
   a.nchunks = cdiv(a.Cin, CC);
+  {
+    static const int dbg = getenv("COCLR_WINO_DEBUG") ? atoi(getenv("COCLR_WINO_DEBUG")) : 0;
+    a.debug = dbg;
+  }
   const size_t stage = ((size_t)16 * CC * 64 + (size_t)CC * a.planeS) * sizeof(float);
   // two stages + statistics partials + window coordinate table
   const size_t lds = 2 * stage + (size_t)2 * 64 * 64 * sizeof(float) + (size_t)PCH * 256 * sizeof(unsigned);
   if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_wino_hw_kernel<CC, PCH>;
+  auto kern = conv_wino_hw_kernel<CC, PCH, X16>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   const long total = (long)a.mtiles * a.ntiles;
@@ -1798,6 +1858,7 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
   int rc = plan_forward(d, &p, &variant);
   if (rc) return rc;
   ConvArgs a;
+  a.debug = 0;
   a.x = x; a.w = w_packed; a.y = y; a.stats = stats; a.bias = bias;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.n_index = n_index;
   a.x_nstride = d->x_nstride; a.y_nstride = d->y_nstride;
@@ -1878,6 +1939,15 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
       if ((((double)(1 << p.lTN)) * (double)a.y_nstride + (double)(a.Cout + 128) * a.y_cstride) * 4.0 >= lim)
         return COCLR_EINVAL;
       if (16.0 * a.CinP * a.CoutP * 4.0 >= lim) return COCLR_EINVAL;
+      {
+        // 16-byte window DMA when every granule of an input row is 16-byte aligned and the widened
+        // window still fits three pieces per channel (LDS: 2 x (32 + 24) KiB of stages)
+        static const bool x16_off = getenv("COCLR_WINO_X16") && atoi(getenv("COCLR_WINO_X16")) == 0;
+        const int gran = ((p.WT * p.WH * (2 * (1 << p.lTW) + 8)) << p.lTN) / 4;
+        const bool x16 = !x16_off && p.lTW >= 1 && (p.Wi % 4) == 0 && (a.x_cstride % 4) == 0 &&
+                         (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 && gran <= 192;
+        if (x16) return launch_wino_hw<8, 3, true>(a, p, stream);
+      }
       return p.plane <= 384 ? launch_wino_hw<8, 6>(a, p, stream) : launch_wino_hw<8, 10>(a, p, stream);
     }
     case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);
