@@ -84,7 +84,24 @@ __device__ __forceinline__ float row16_sum(float v) {
 // exact floor(e / d) for 0 <= e < 2^20 given inv = 1.0f / d
 __device__ __forceinline__ int fdiv(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
 
-template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false>
+// LDS-DMA of 4 / 16 bytes per lane as plain __device__ functions: inside a template (the kernels' lambdas
+// are implicitly __host__ __device__ and re-checked at instantiation) the host pass, which has no
+// gfx950 features, rejects the 16-byte size.
+__device__ __forceinline__ void dma4_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voff,
+                                            unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_dst), 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voff,
+                                             unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
+}
+
+// XG: spatial stencils (kw = 3, stride 1, pad 1, no dilation) stage their window with 16-BYTE LDS-DMA:
+// rows are widened to whole 16-byte granules of the input row (global columns [ow0 - 4, ow0 + TW + 4),
+// so window column 0 sits at LDS column 3), a lane of a DMA piece moves one granule, and a 10x10 window
+// takes ONE piece per channel instead of two scattered 4-byte ones.  a.WW / a.plane1 are then the padded
+// row / sample extents in floats, a.plane the number of granules, a.inv_* reciprocals in granules.
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false, bool XG = false>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvArgs a) {
   constexpr int TAPS = KT * KH * KW;
@@ -136,20 +153,23 @@ conv_igemm_kernel(const ConvArgs a) {
   // ---- per-lane byte offsets of the window elements this lane's DMA pieces fetch ----
   unsigned goff[PCH];
   {
-    const int hw = a.WH * a.WW;
-    const bool dil = (a.dt | a.dh | a.dw) != 1;
+    const int rowlen = XG ? a.WW >> 2 : a.WW;          // XG: in granules
+    const int hw = a.WH * rowlen;
+    const int p1 = XG ? a.plane1 >> 2 : a.plane1;
+    const bool dil = !XG && (a.dt | a.dh | a.dw) != 1;
 #pragma unroll
     for (int j = 0; j < PCH; ++j) {
       const int e = j * 64 + lane;
       unsigned off = OOB;
       if (e < plane) {
         const int wn_ = fdiv(e, a.inv_plane1);
-        int q = e - wn_ * a.plane1;
+        int q = e - wn_ * p1;
         const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
         const int wh = fdiv(q, a.inv_ww);
-        const int ww = q - wh * a.WW;
+        const int ww = q - wh * rowlen;
         const int n = n0 + wn_;
-        int it = vt0 + wt, ih = vh0 + wh, iw = vw0 + ww;
+        // XG: granule g of a row starts at column ow0 - 4 + 4g: wholly inside or outside (Wi % 4 == 0)
+        int it = vt0 + wt, ih = vh0 + wh, iw = XG ? vw0 - 3 + 4 * ww : vw0 + ww;
         bool ok = n < a.N && it >= 0 && ih >= 0 && iw >= 0;
         if (dil && ok) {
           const int vt = it, vh = ih, vw = iw;
@@ -205,7 +225,7 @@ conv_igemm_kernel(const ConvArgs a) {
     const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
     const int tn = p >> (a.lTW + a.lTH + a.lTT);
     lanebase[nf] = W_FLOATS + tn * a.plane1 + ((tt * a.st) * a.WH + th * a.sh) * a.WW +
-                   tw * a.sw + half * planeS;
+                   tw * a.sw + half * planeS + (XG ? 3 : 0);
   }
   const int abase = half * BM + wm * (BM / WM) + l31;
 
@@ -247,14 +267,21 @@ conv_igemm_kernel(const ConvArgs a) {
         const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
 #pragma unroll
         for (int j = 0; j < PCH; ++j)
-          if (j * 64 < plane)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
-                                                     goff[j], soff, 0, 0);
+          if (j * 64 < plane) {
+            if (XG) dma16_to_lds(rx, xs + c * planeS + j * 256, goff[j], soff);
+            else dma4_to_lds(rx, xs + c * planeS + j * 64, goff[j], soff);
+          }
       } else {
         // channel past Cin: its packed weights are zero, keep the operand finite
 #pragma unroll
         for (int j = 0; j < PCH; ++j)
-          if (j * 64 < plane) xs[c * planeS + j * 64 + lane] = 0.f;
+          if (j * 64 < plane) {
+            if (XG)
+              *reinterpret_cast<float4*>(&xs[c * planeS + j * 256 + lane * 4]) =
+                  make_float4(0.f, 0.f, 0.f, 0.f);
+            else
+              xs[c * planeS + j * 64 + lane] = 0.f;
+          }
       }
     }
   };
@@ -737,18 +764,6 @@ __device__ __forceinline__ float agpr_read(float x) {
 }
 
 constexpr int kWinoGrid = 256;    // persistent grid: one workgroup per CU
-
-// LDS-DMA of 4 / 16 bytes per lane as plain __device__ functions: inside a template (the kernels' lambdas
-// are implicitly __host__ __device__ and re-checked at instantiation) the host pass, which has no
-// gfx950 features, rejects the 16-byte size.
-__device__ __forceinline__ void dma4_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voff,
-                                            unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_dst), 4, voff, soff, 0, 0);
-}
-__device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned voff,
-                                             unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
-}
 
 // X16: the window is staged with 16-BYTE LDS-DMA.  Its rows are widened to whole 16-byte granules of
 // the input row (global columns [2*ow0 - 4, 2*ow0 + 2*TW + 4): the patch of block b then starts at the
@@ -1619,19 +1634,36 @@ pack_weights_batch_kernel(const int64_t* __restrict__ table, const int32_t* __re
 
 inline int pad_to(int v, int m) { return ((v + m - 1) / m) * m; }
 
-template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false>
+// granules of the widened window of a kw = 3 / stride-1 stencil (see XG above)
+inline int granule_count(const ConvPlan& p) {
+  return ((p.WT * p.WH * ((1 << p.lTW) + 8)) << p.lTN) / 4;
+}
+
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false, bool XG = false>
 int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   constexpr int TAPS = KT * KH * KW;
-  if (p.plane > PCH * 64) return COCLR_EINVAL;
   a.mtiles = cdiv(a.Cout, BM);
-  a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;    // 16-byte staging packs rows back to back
+  if (XG) {
+    const int wwp = (1 << p.lTW) + 8;
+    a.WW = wwp;
+    a.plane1 = p.WT * p.WH * wwp;
+    a.plane = (a.plane1 << p.lTN) / 4;
+    if (a.plane > PCH * 64) return COCLR_EINVAL;
+    a.planeS = cdiv(a.plane, 64) * 256;
+    a.inv_plane1 = 1.0f / (float)(a.plane1 / 4);
+    a.inv_hw = 1.0f / (float)(p.WH * (wwp / 4));
+    a.inv_ww = 1.0f / (float)(wwp / 4);
+  } else {
+    if (p.plane > PCH * 64) return COCLR_EINVAL;
+    a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;    // 16-byte staging packs rows back to back
+  }
   a.nchunks = cdiv(a.Cin, CC);
   const size_t stage = ((size_t)TAPS * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
   const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
   const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PCH, XV4>;
+  auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   const long blocks = (long)a.mtiles * a.ntiles;
@@ -1900,6 +1932,12 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
   const bool xv4 = d->kh == 1 && d->kw == 1 && p.Hi == 1 && p.WH == 1 && p.sw == 1 && p.lTW >= 2 &&
                    p.dt == 1 && p.dh == 1 && p.dw == 1 && (p.Wi % 4) == 0 && (p.plane % 4) == 0 &&
                    (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0;
+  // (1,3,3) stride-1 pad-1 undilated stencils on rows of whole 16-byte granules: 16-byte window DMA
+  static const bool xg_off = getenv("COCLR_CONV_XG") && atoi(getenv("COCLR_CONV_XG")) == 0;
+  const bool xg = !xg_off && d->kt == 1 && d->kh == 3 && d->kw == 3 && p.sw == 1 && p.sh == 1 &&
+                  p.st == 1 && p.pw == 1 && p.dt == 1 && p.dh == 1 && p.dw == 1 && p.lTW >= 2 &&
+                  (p.Wi % 4) == 0 && (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 &&
+                  ((uintptr_t)x % 16) == 0 && granule_count(p) <= 192;
   switch (variant) {
     case 0:  return xv4 ? launch_variant<1, 1, 1, 32, 128, 128, 2, true>(a, p, stream)
                         : launch_variant<1, 1, 1, 32, 128, 128, 2>(a, p, stream);
@@ -1908,10 +1946,14 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
     case 2:  return xv4 ? launch_variant<1, 1, 1, 32, 64, 64, 1, true>(a, p, stream)
                         : launch_variant<1, 1, 1, 32, 64, 64, 1>(a, p, stream);
     case 3:  return launch_variant<1, 1, 1, 16, 64, 64, 4>(a, p, stream);
-    case 10: return launch_variant<1, 3, 3, 4, 128, 128, 4>(a, p, stream);
-    case 11: return launch_variant<1, 3, 3, 8, 64, 128, 4>(a, p, stream);
-    case 12: return launch_variant<1, 3, 3, 8, 64, 64, 4>(a, p, stream);
-    case 13: return launch_variant<1, 3, 3, 8, 64, 64, 8>(a, p, stream);
+    case 10: return xg ? launch_variant<1, 3, 3, 4, 128, 128, 3, false, true>(a, p, stream)
+                       : launch_variant<1, 3, 3, 4, 128, 128, 4>(a, p, stream);
+    case 11: return xg ? launch_variant<1, 3, 3, 8, 64, 128, 3, false, true>(a, p, stream)
+                       : launch_variant<1, 3, 3, 8, 64, 128, 4>(a, p, stream);
+    case 12: return xg ? launch_variant<1, 3, 3, 8, 64, 64, 3, false, true>(a, p, stream)
+                       : launch_variant<1, 3, 3, 8, 64, 64, 4>(a, p, stream);
+    case 13: return xg ? launch_variant<1, 3, 3, 8, 64, 64, 3, false, true>(a, p, stream)
+                       : launch_variant<1, 3, 3, 8, 64, 64, 8>(a, p, stream);
     case 20: return xv4 ? launch_variant<3, 1, 1, 4, 128, 128, 4, true>(a, p, stream)
                         : launch_variant<3, 1, 1, 4, 128, 128, 4>(a, p, stream);
     case 21: return xv4 ? launch_variant<3, 1, 1, 8, 64, 128, 4, true>(a, p, stream)
