@@ -69,7 +69,6 @@ struct ConvArgs {
   float inv_plane1, inv_hw, inv_ww;
   int mtiles, ntiles, nchunks;
   int relu, accumulate;
-  int debug;             // timing ablations of the Winograd kernel (COCLR_WINO_DEBUG; wrong results)
 };
 
 // sum over each 16-lane row (result in every lane of the row)
@@ -767,12 +766,13 @@ constexpr int kWinoGrid = 256;    // persistent grid: one workgroup per CU
 
 // X16: the window is staged with 16-BYTE LDS-DMA.  Its rows are widened to whole 16-byte granules of
 // the input row (global columns [2*ow0 - 4, 2*ow0 + 2*TW + 4): the patch of block b then starts at the
-// odd LDS column 3 + 2b), every lane of a DMA piece moves one granule, and a window of ~100 granules
-// takes TWO pieces per channel instead of six 4-byte ones.  The scattered 4-byte pieces are what the
-// kernel waits for (timing ablations: no window DMA -16 %, no weight DMA -4 %: a piece whose lanes
-// gather 18-float rows costs its wave ~5x a contiguous 1-KiB piece).  Needs Wi % 4 == 0 and 16-byte
-// aligned sample / channel strides; a.WW, a.plane1 are then the PADDED row / sample extents in floats,
-// a.plane the number of granules, a.inv_* the reciprocals in granule units.
+// odd LDS column 3 + 2b and is read as three aligned 8-byte pairs whose outer halves are unused), every
+// lane of a DMA piece moves one granule, and a window of ~100 granules takes TWO pieces per channel
+// instead of six 4-byte ones.  Measured at B=32 (same box, alternating): Conv_2c.conv1 0.790 -> 0.781 ms
+// forward, 0.686 -> 0.671 data gradient; Mixed_3c.b1.conv1 0.330 -> 0.318 / 0.322 -> 0.307;
+// Mixed_3b.b1.conv1 0.175 -> 0.170 / 0.217 -> 0.208.  Needs Wi % 4 == 0 and 16-byte aligned sample /
+// channel strides; a.WW, a.plane1 are then the PADDED row / sample extents in floats, a.plane the
+// number of granules, a.inv_* the reciprocals in granule units.
 template <int CC, int PCH, bool X16 = false>
 __global__ void __launch_bounds__(256)
 conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
@@ -890,7 +890,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   // DMA of one chunk into stage `sbase`.  Weights: the packed operand is [cin][cout][16 xi], so a
   // channel row of the 64-cout tile is 4 KiB = four 1 KiB pieces, copied verbatim.
   auto stage = [&](int cin0, float* sbase) {
-    if (!(a.debug & 2)) {
+    {
       // piece p = wave + 4k is quarter `wave` of channel row k: both offsets advance by constants
       unsigned soff = (unsigned)((((long)cin0 * a.CoutP + cout0) * 16 + wave * 256) * 4);
       const unsigned sstep = (unsigned)a.CoutP * 64u;
@@ -903,7 +903,6 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
       }
     }
     float* xs = sbase + W_FLOATS;
-    if (a.debug & 1) return;
 #pragma unroll
     for (int ci = 0; ci < CC / 4; ++ci) {
       const int c = ci * 4 + wave;
@@ -994,10 +993,14 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
         for (int rr = 0; rr < 4; ++rr) {
           const float* src = &cur[lanebase + rr * WW + 2 * q * planeS];
           if (X16) {
-            // odd column: the middle pair is the aligned 8-byte read, the ends one ds_read2_b32
+            // odd column: three aligned 8-byte reads around it (one ds_read2_b64 + one ds_read_b64),
+            // the outer halves unused -- 4-byte reads of columns two apart would use every other
+            // LDS bank (PMC: 40 % of the LDS cycles conflicts)
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(src - 1);
             const f32x2 mid = *reinterpret_cast<const f32x2*>(src + 1);
-            dv[2 * rr].x = src[0]; dv[2 * rr].y = mid.x;
-            dv[2 * rr + 1].x = mid.y; dv[2 * rr + 1].y = src[3];
+            const f32x2 hi = *reinterpret_cast<const f32x2*>(src + 3);
+            dv[2 * rr].x = lo.y; dv[2 * rr].y = mid.x;
+            dv[2 * rr + 1].x = mid.y; dv[2 * rr + 1].y = hi.x;
           } else {
             dv[2 * rr] = *reinterpret_cast<const f32x2*>(src);
             dv[2 * rr + 1] = *reinterpret_cast<const f32x2*>(src + 2);
@@ -1127,17 +1130,16 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
       }
     };
     const bool fancy = a.bias || a.ep_scale || a.relu || a.accumulate;
-    if (a.debug & 4) {}
-    else if (fancy) emit(std::integral_constant<int, 2>{});
-    else if (want_stats && !(a.debug & 8)) emit(std::integral_constant<int, 1>{});
+    if (fancy) emit(std::integral_constant<int, 2>{});
+    else if (want_stats) emit(std::integral_constant<int, 1>{});
     else emit(std::integral_constant<int, 0>{});
     pend_ry = ry;
     pend_vo0 = yvoff;
     pend_vo1 = pvalid ? yvoff + row_bytes : OOB;
     pend_co0 = e_cout0 + wm * 32;
-    pending = !(a.debug & 4);
+    pending = true;
 
-    if (want_stats && !(a.debug & 12)) {
+    if (want_stats) {
       __syncthreads();
       // thread t: row t>>2, quarter t&3 of its 64 partials; the quarters meet through DPP
       const int row = tid >> 2, qtr = tid & 3;
@@ -1186,10 +1188,6 @@ int launch_wino_hw(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
     a.planeS = cdiv(p.plane, 64) * 64;
   }
   a.nchunks = cdiv(a.Cin, CC);
-  {
-    static const int dbg = getenv("COCLR_WINO_DEBUG") ? atoi(getenv("COCLR_WINO_DEBUG")) : 0;
-    a.debug = dbg;
-  }
   const size_t stage = ((size_t)16 * CC * 64 + (size_t)CC * a.planeS) * sizeof(float);
   // two stages + statistics partials + window coordinate table
   const size_t lds = 2 * stage + (size_t)2 * 64 * 64 * sizeof(float) + (size_t)PCH * 256 * sizeof(unsigned);
@@ -1890,7 +1888,6 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
   int rc = plan_forward(d, &p, &variant);
   if (rc) return rc;
   ConvArgs a;
-  a.debug = 0;
   a.x = x; a.w = w_packed; a.y = y; a.stats = stats; a.bias = bias;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.n_index = n_index;
   a.x_nstride = d->x_nstride; a.y_nstride = d->y_nstride;
