@@ -28,7 +28,7 @@ Legs (all in the one JSON line):
                            still in backward), i.e. the per-rank cost the scaling curve starts from
   value_caller_optimizer   the same step with torch's OWN Adam over the same 470 groups and
                            nn.CrossEntropyLoss (COCLR_PATCH_ADAM=0)
-  roofline        dominant kernel (Conv_2c.conv1, spatial Winograd): MFMA FLOPs ACTUALLY ISSUED / time
+  roofline        dominant kernel (Conv_2c.conv1, spatial Winograd, 16-byte window DMA): MFMA FLOPs ACTUALLY ISSUED / time
                   / 157.3 TF, in-step (HIP events on the launch stream) and isolated; the
                   direct-convolution-equivalent figure is kept as `direct_equiv`
   roofline_hbm    largest BatchNorm+ReLU apply launch (Conv_1a.bn1): algorithmic bytes / time / 8 TB/s
@@ -201,7 +201,9 @@ def nce_roofline(device, B):
            "algorithmic_mb_per_launch": round(byts / 1e6, 2),
            "tflops": round(flop / us / 1e6, 2),
            "mfma_frac_of_fp32_peak": round(flop / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 4)}
-    pj = os.path.join(ROOT, "profiles", "r02_nce_pmc.json")
+    pj = os.path.join(ROOT, "profiles", "r03_nce_pmc.json")
+    if not os.path.exists(pj):
+        pj = os.path.join(ROOT, "profiles", "r02_nce_pmc.json")
     if os.path.exists(pj):
         rec["pmc"] = json.load(open(pj))
     return rec
@@ -432,7 +434,9 @@ def main():
         issued = flops * 16.0 / 36.0                             # F(2x2,3x3): 16 of 36 products
         roof = None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath) and args.net == "s3d" and B == 32:
             # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
             # (counters cannot be read from inside the process)
@@ -446,7 +450,8 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic,
-                    "kernel": "conv_wino_hw_kernel<8,6> Winograd F(2x2,3x3) (Conv_2c.conv1 64->192, "
+                    "kernel": "conv_wino_hw_kernel<8,3,true> Winograd F(2x2,3x3), 16-byte window DMA "
+                              "(Conv_2c.conv1 64->192, "
                               "%dx%dx%d, N=%d; the query encoder's forward launches inside the timed "
                               "steps, sharing the chip with the key-encoder stream)" % (tq, hq, hq, B),
                     "launches_timed": nk, "avg_launch_ms": round(kms, 4),

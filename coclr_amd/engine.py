@@ -161,13 +161,26 @@ class PackPlan:
         return True
 
 
+# While a differentiated pass is being captured into a hipGraph (GRAPH_QUERY below) the capture stream
+# stands for the stream the graph will be replayed on: packed-operand buffers and re-layout plans
+# recorded by the eager passes on that stream are the ones the captured kernels use.
+_STREAM_ALIAS = {}
+
+
+def _stream_key(device):
+    if device.type != "cuda":
+        return 0
+    st = torch.cuda.current_stream(device).cuda_stream
+    return _STREAM_ALIAS.get(st, st)
+
+
 def _plan_for(module, save, device):
     if not BATCH_PACK:
         return None
     plans = module.__dict__.get("_coclr_packplans")
     if plans is None:
         plans = module.__dict__["_coclr_packplans"] = {}
-    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    stream = _stream_key(device)
     key = (bool(save), stream, device)
     plan = plans.get(key)
     if plan is None:
@@ -375,7 +388,8 @@ class Run:
         # references (one event query per window, so the host cost stays negligible while the
         # peak is activations + a few windows of dy instead of activations + ALL dy).
         self._side_calls += 1
-        if _SIDE_WINDOW and self._side_calls % _SIDE_WINDOW == 0 and self._side_keep:
+        if _SIDE_WINDOW and self._side_calls % _SIDE_WINDOW == 0 and self._side_keep and \
+                not torch.cuda.is_current_stream_capturing():
             ev = torch.cuda.Event()
             ev.record(st)
             self._side_windows.append((ev, self._side_keep))
@@ -409,9 +423,9 @@ class Run:
         elif self.cur_lane is not None and self._parent is not None:
             # inside a lane: the buffers (and the batch re-layout that fills them) belong to the parent
             # stream, which the lane stream waited for when it forked
-            stream = self._parent.cuda_stream
+            stream = _STREAM_ALIAS.get(self._parent.cuda_stream, self._parent.cuda_stream)
         else:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stream = _stream_key(self.device)
         key = (tag, n, stream, self.device)
         buf = store[1].get(key)
         if buf is None:
@@ -856,6 +870,188 @@ class EngineFn(torch.autograd.Function):
         return (None, None, dx) + grads
 
 
+# ---------------------------------------------------------------------------------
+# hipGraph replay of a DIFFERENTIATED pass (the query encoder's forward and backward)
+# ---------------------------------------------------------------------------------
+# The launch sequence of a module pass is static per input shape: ~330 launches forward, ~600
+# backward, ~18 ms of host work per training step between them (bench.py `host_floor_ms_per_step`).
+# With COCLR_GRAPH_QUERY=1 a module that has been run eagerly a few times with an unchanged signature is
+# captured -- forward and, at the first backward after that, its tape -- into two hipGraphs that share
+# one private memory pool, and every later step is: copy the input into the graph's static buffer,
+# replay, hand autograd fresh aliases of the static outputs / gradients.  Gradients that live in
+# DistributedDataParallel's buckets (grad_out) are written there by the captured kernels as well.
+# Same kernels, same order, same operands as the eager pass: results are bit-identical
+# (tests/test_gpu_model.py::test_graphed_query_encoder_matches_eager).
+GRAPH_QUERY = os.environ.get("COCLR_GRAPH_QUERY", "0") == "1"
+_GRAPH_WARMUP = 2           # eager passes with an unchanged signature before capturing
+_STATIC_PTRS = set()        # addresses of static graph outputs (a later stage takes them in place)
+_CAPTURE_STREAMS = {}
+
+
+class _GraphEntry:
+    __slots__ = ("sig", "seen", "fwd", "bwd", "pool", "x", "out", "dout", "grads", "dx", "run", "xin",
+                 "version", "params", "need_dx", "disabled", "static_in", "static_dout")
+
+    def __init__(self, sig):
+        self.sig, self.seen = sig, 0
+        self.fwd = self.bwd = self.pool = None
+        self.version = 0
+        self.disabled = False
+        self.grads = self.dx = self.run = self.xin = self.x = self.out = self.dout = None
+        self.static_in = self.static_dout = None
+        self.params, self.need_dx = (), False
+
+
+def _graph_signature(module, x, params, kwargs):
+    bns = module.__dict__.get("_coclr_bn_list")
+    if bns is None:
+        bns = module.__dict__["_coclr_bn_list"] = [
+            m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    slots = tuple(_GRAD_SLOTS[id(p)][1].data_ptr() if id(p) in _GRAD_SLOTS else 0 for p in params)
+    return (tuple(x.shape), x.dtype, x.device, bool(x.requires_grad), tuple(sorted(kwargs)),
+            tuple(p.data_ptr() for p in params), tuple(bool(p.requires_grad) for p in params), slots,
+            tuple((m.training, m.momentum, m.eps, m.running_mean.data_ptr()) for m in bns))
+
+
+def _capture_stream(device):
+    st = _CAPTURE_STREAMS.get(device)
+    if st is None:
+        st = _CAPTURE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _copy_rows(src, dst):
+    """dst (dense) <- src (dense rows, possibly strided along dim 0) as one kernel."""
+    ident = _IDENT.get((src.device, src.shape[0]))
+    if ident is None:
+        ident = _IDENT[(src.device, src.shape[0])] = torch.arange(src.shape[0], device=src.device)
+    ops.gather_rows(src, ident, dst)
+
+
+_IDENT = {}
+
+
+def _graph_entry(module, x, params, kwargs):
+    """The captured entry to replay for this call, or None (run eagerly)."""
+    if kwargs or not x.is_cuda or x.dim() != 5 or torch.cuda.is_current_stream_capturing():
+        return None
+    store = module.__dict__.get("_coclr_graph_entries")
+    if store is None:
+        store = module.__dict__["_coclr_graph_entries"] = {}
+    sig = _graph_signature(module, x, params, kwargs)
+    key = (tuple(x.shape), bool(x.requires_grad))
+    ent = store.get(key)
+    if ent is None or ent.sig != sig:
+        ent = store[key] = _GraphEntry(sig)      # new shape / moved storage / flags changed: start over
+    if ent.disabled:
+        return None
+    ent.seen += 1
+    if ent.seen <= _GRAPH_WARMUP:
+        return None
+    if ent.fwd is None:
+        _capture_forward(module, x, params, ent)
+    return ent
+
+
+def _capture_forward(module, x, params, ent):
+    dev = x.device
+    need_dx = bool(x.requires_grad)
+    cap = _capture_stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    # the input of a later stage is the previous stage's static output: same address every step
+    if _dense5(x) and x.data_ptr() in _STATIC_PTRS:
+        static_x, ent.static_in = x.detach(), True
+    else:
+        static_x, ent.static_in = torch.empty(x.shape, dtype=x.dtype, device=dev), None
+        _copy_rows(x.detach(), static_x)
+    cur.synchronize()
+    pool = torch.cuda.graph_pool_handle()
+    g = torch.cuda.CUDAGraph()
+    _STREAM_ALIAS[cap.cuda_stream] = cur.cuda_stream
+    try:
+        with torch.cuda.graph(g, pool=pool, stream=cap, capture_error_mode="thread_local"):
+            run = Run(dev, save=True, need_input_grad=need_dx)
+            xin = Val(static_x)
+            if not need_dx:
+                run.no_grad_bases.add(id(xin.base))
+            run.begin(module)
+            run.out = module._emit(run, xin)
+            out = run.out.view()
+    finally:
+        _STREAM_ALIAS.pop(cap.cuda_stream, None)
+    ent.fwd, ent.pool, ent.x, ent.out, ent.run, ent.xin = g, pool, static_x, out, run, xin
+    ent.params, ent.need_dx = params, need_dx
+    ent.bwd = None
+    _STATIC_PTRS.add(out.data_ptr())
+
+
+class GraphedFn(torch.autograd.Function):
+    """EngineFn whose forward and backward are hipGraph replays (see GRAPH_QUERY)."""
+
+    @staticmethod
+    def forward(ctx, ent, x, *params):
+        if ent.static_in is None or x.data_ptr() != ent.x.data_ptr():
+            _copy_rows(x.detach(), ent.x)
+        ent.fwd.replay()
+        ent.version += 1
+        ctx.ent, ctx.version = ent, ent.version
+        return ent.out.detach()
+
+    @staticmethod
+    def backward(ctx, dout):
+        ent = ctx.ent
+        if ctx.version != ent.version:
+            raise RuntimeError(
+                "coclr_amd: backward through a graph-replayed encoder pass whose activations a later "
+                "forward has overwritten (two forwards, then two backwards); set COCLR_GRAPH_QUERY=0")
+        ctx.ent = None
+        params = ent.params
+        # A caller that accumulates gradients still holds last step's `.grad`, which aliases the static
+        # buffer this replay overwrites: give it its own memory first (rare: zero_grad() sets None)
+        if ent.grads is not None:
+            for p, g in zip(params, ent.grads):
+                if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                    p.grad = p.grad.clone()
+        if ent.bwd is None:
+            _capture_backward(ent, dout)
+        elif ent.static_dout is None or dout.data_ptr() != ent.dout.data_ptr():
+            ent.dout.copy_(dout)
+        ent.bwd.replay()
+        grads = tuple(None if g is None else g.view_as(g) for g in ent.grads)
+        dx = ent.dx.view_as(ent.dx) if ent.dx is not None else None
+        return (None, dx) + grads
+
+
+def _capture_backward(ent, dout):
+    dev = dout.device
+    cap = _capture_stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    # the gradient of an earlier stage's output is a later stage's static dx: same address every step
+    if dout.is_contiguous() and dout.data_ptr() in _STATIC_PTRS:
+        static_dout, ent.static_dout = dout.detach(), True
+    else:
+        static_dout, ent.static_dout = torch.empty(ent.out.shape, dtype=dout.dtype, device=dev), None
+        static_dout.copy_(dout)
+    cur.synchronize()
+    run = ent.run
+    g = torch.cuda.CUDAGraph()
+    _STREAM_ALIAS[cap.cuda_stream] = cur.cuda_stream
+    try:
+        with torch.cuda.graph(g, pool=ent.pool, stream=cap, capture_error_mode="thread_local"):
+            run.backward(static_dout)
+            dx = run.grads.pop(id(ent.xin.base), None) if ent.need_dx else None
+            grads = tuple(run.param_grads.pop(id(p), None) if p.requires_grad else None
+                          for p in ent.params)
+            run.param_grads.clear()
+            run.grads.clear()
+    finally:
+        _STREAM_ALIAS.pop(cap.cuda_stream, None)
+    ent.bwd, ent.dout, ent.grads, ent.dx = g, static_dout, grads, dx
+    ent.run = None           # the tape has been consumed; its tensors live on in the graphs' pool
+    if dx is not None:
+        _STATIC_PTRS.add(dx.data_ptr())
+
+
 def _dense5(t):
     n, c, d, h, w = t.shape
     s = t.stride()
@@ -868,6 +1064,10 @@ def run_module(module, x, **kwargs):
     if params is None:
         params = module.__dict__["_coclr_params"] = list(module.parameters())
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        if GRAPH_QUERY:
+            ent = _graph_entry(module, x, params, kwargs)
+            if ent is not None:
+                return GraphedFn.apply(ent, x, *params)
         return EngineFn.apply(module, kwargs, x, *params)
     run = Run(x.device, save=False)
     xin = Val(x if _dense5(x) else x.contiguous())

@@ -210,3 +210,55 @@ def test_graph_replay_matches_eager():
     sd_g, sd_e = models[0].state_dict(), models[1].state_dict()
     for k in sd_g:
         assert torch.equal(sd_g[k], sd_e[k]), k
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_graphed_query_encoder_matches_eager(split, monkeypatch):
+    """COCLR_GRAPH_QUERY=1: after two eager passes the query encoder's forward AND backward (the tape,
+    with its weight-gradient side stream) are captured into hipGraphs and replayed.  Same kernels, same
+    order, same operands: logits of every step and all parameters after six Adam steps must be BIT-
+    identical to the eager run -- as one autograd node (world size 1) and as one node per backbone
+    stage (the world > 1 structure, where stage k's static output / input gradient feed stage k+1 /
+    k-1 in place)."""
+    import copy
+    import torch.nn.functional as F
+    import model.pretrain as product
+    from coclr_amd import engine
+    from coclr_amd.backbone import s3dg
+    monkeypatch.setattr(s3dg, "_SPLIT_MODE", "1" if split else "0")
+    gold = load_golden("infonce_s3d_small")
+    cfg = gold["cfg"]
+    base = build_model(cfg, product)
+    results = []
+    for graphed in (False, True):
+        monkeypatch.setattr(engine, "GRAPH_QUERY", graphed)
+        model = copy.deepcopy(base).cuda().train()
+        opt = torch.optim.Adam([{"params": p} for _, p in model.named_parameters()], lr=1e-3,
+                               weight_decay=1e-5)
+        outs = []
+        for step in range(6):
+            blocks, _ = case_inputs(cfg, step % cfg["steps"])
+            torch.manual_seed(cfg["perm_seed"] + step)
+            out, tgt = model(blocks[0].cuda())
+            loss = F.cross_entropy(out, tgt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            outs.append(out.detach().clone())
+        torch.cuda.synchronize()
+        if graphed:
+            mods = [model.encoder_q[0]] if not split else [getattr(model.encoder_q[0], "block%d" % i)
+                                                           for i in range(1, 6)]
+            for m in mods:
+                ents = list(m.__dict__["_coclr_graph_entries"].values())
+                assert any(e.fwd is not None and e.bwd is not None for e in ents), \\
+                    "the pass was never captured"
+        results.append((outs, [p.detach().clone() for p in model.parameters()],
+                        {k: v.clone() for k, v in model.state_dict().items()}))
+    (o_e, p_e, sd_e), (o_g, p_g, sd_g) = results
+    for step, (a, b) in enumerate(zip(o_e, o_g)):
+        assert torch.equal(a, b), "logits of step %d" % step
+    for a, b in zip(p_e, p_g):
+        assert torch.equal(a, b)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
