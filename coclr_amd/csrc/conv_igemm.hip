@@ -773,7 +773,7 @@ constexpr int kWinoGrid = 256;    // persistent grid: one workgroup per CU
 // Mixed_3b.b1.conv1 0.175 -> 0.170 / 0.217 -> 0.208.  Needs Wi % 4 == 0 and 16-byte aligned sample /
 // channel strides; a.WW, a.plane1 are then the PADDED row / sample extents in floats, a.plane the
 // number of granules, a.inv_* the reciprocals in granule units.
-template <int CC, int PCH, bool X16 = false>
+template <int CC, int PCH, bool X16 = false, int ABL = 0>
 __global__ void __launch_bounds__(256)
 conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   constexpr int TAPS = 16;
@@ -890,7 +890,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   // DMA of one chunk into stage `sbase`.  Weights: the packed operand is [cin][cout][16 xi], so a
   // channel row of the 64-cout tile is 4 KiB = four 1 KiB pieces, copied verbatim.
   auto stage = [&](int cin0, float* sbase) {
-    {
+    if (!(ABL & 2)) {
       // piece p = wave + 4k is quarter `wave` of channel row k: both offsets advance by constants
       unsigned soff = (unsigned)((((long)cin0 * a.CoutP + cout0) * 16 + wave * 256) * 4);
       const unsigned sstep = (unsigned)a.CoutP * 64u;
@@ -903,6 +903,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
       }
     }
     float* xs = sbase + W_FLOATS;
+    if (ABL & 1) return;
 #pragma unroll
     for (int ci = 0; ci < CC / 4; ++ci) {
       const int c = ci * 4 + wave;
@@ -982,6 +983,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
       // into V[(q+1)&1], the patch of step q+2 is fetched into dv, and each weight quad of av is
       // refilled for step q+1 as soon as its four MFMAs have gone.
       auto fetch_a_quad = [&](int q, int g, float (&av)[16]) {
+        if (ABL & 32) { if (q == 0) { av[4 * g] = av[4 * g + 1] = av[4 * g + 2] = av[4 * g + 3] = 1.f + g; } return; }
         const float4 v = *reinterpret_cast<const float4*>(
             &cur[abase + 2 * q * BM * 16 + ((g + arot) & 3) * 4]);
         av[4 * g + 0] = v.x; av[4 * g + 1] = v.y; av[4 * g + 2] = v.z; av[4 * g + 3] = v.w;
@@ -989,6 +991,10 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
       // patch rows as two column pairs (the ds_read_b64 granules): the row pass of B^T d B is then
       // elementwise on pairs, the column pass plain scalar ops on their halves
       auto fetch_d = [&](int q, f32x2 (&dv)[8]) {
+        if (ABL & 16) {
+          if (q == 0) for (int rr = 0; rr < 8; ++rr) { dv[rr].x = 1.f + rr; dv[rr].y = 2.f; }
+          return;
+        }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const float* src = &cur[lanebase + rr * WW + 2 * q * planeS];
@@ -1008,6 +1014,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
         }
       };
       auto transform = [&](const f32x2 (&dv)[8], float (&V)[16]) {
+        if (ABL & 16) { for (int i = 0; i < 16; ++i) V[i] = dv[i & 7].x; return; }
         f32x2 tl[4], th[4];
         tl[0] = dv[0] - dv[4]; th[0] = dv[1] - dv[5];
         tl[1] = dv[2] + dv[4]; th[1] = dv[3] + dv[5];
@@ -1131,7 +1138,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
     };
     const bool fancy = a.bias || a.ep_scale || a.relu || a.accumulate;
     if (fancy) emit(std::integral_constant<int, 2>{});
-    else if (want_stats) emit(std::integral_constant<int, 1>{});
+    else if (want_stats && !(ABL & 8)) emit(std::integral_constant<int, 1>{});
     else emit(std::integral_constant<int, 0>{});
     pend_ry = ry;
     pend_vo0 = yvoff;
@@ -1139,7 +1146,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
     pend_co0 = e_cout0 + wm * 32;
     pending = true;
 
-    if (want_stats) {
+    if (want_stats && !(ABL & 8)) {
       __syncthreads();
       // thread t: row t>>2, quarter t&3 of its 64 partials; the quarters meet through DPP
       const int row = tid >> 2, qtr = tid & 3;
@@ -1168,7 +1175,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
   flush(std::integral_constant<int, 8>{});
 }
 
-template <int CC, int PCH, bool X16 = false>
+template <int CC, int PCH, bool X16 = false, int ABL = 0>
 int launch_wino_hw(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   if (p.WW > 255 || p.WH > 255 || p.WT > 255 || p.lTN > 7) return COCLR_EINVAL;
   a.mtiles = cdiv(a.Cout, 64);
@@ -1192,7 +1199,7 @@ int launch_wino_hw(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   // two stages + statistics partials + window coordinate table
   const size_t lds = 2 * stage + (size_t)2 * 64 * 64 * sizeof(float) + (size_t)PCH * 256 * sizeof(unsigned);
   if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_wino_hw_kernel<CC, PCH, X16>;
+  auto kern = conv_wino_hw_kernel<CC, PCH, X16, ABL>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   const long total = (long)a.mtiles * a.ntiles;
@@ -1985,7 +1992,26 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
         const int gran = ((p.WT * p.WH * (2 * (1 << p.lTW) + 8)) << p.lTN) / 4;
         const bool x16 = !x16_off && p.lTW >= 1 && (p.Wi % 4) == 0 && (a.x_cstride % 4) == 0 &&
                          (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 && gran <= 192;
-        if (x16) return launch_wino_hw<8, 3, true>(a, p, stream);
+        if (x16) {
+#ifdef COCLR_WINO_ABLATE
+          // timing ablations (wrong results by design; build with -DCOCLR_WINO_ABLATE, tools/wino_ablate.sh):
+          // 1 no window DMA, 2 no weight DMA, 8 no statistics, 16 no patch reads + input transform,
+          // 32 no weight reads.  Measured at B=32 on Conv_2c.conv1 forward (0.797 ms): 1 -> 0.737,
+          // 2 -> 0.782, 3 -> 0.673, 8 -> 0.785, 16 -> 0.682, 32 -> 0.755, 48 -> 0.555.
+          static const int abl = getenv("COCLR_WINO_ABL") ? atoi(getenv("COCLR_WINO_ABL")) : 0;
+          switch (abl) {
+            case 1: return launch_wino_hw<8, 3, true, 1>(a, p, stream);
+            case 2: return launch_wino_hw<8, 3, true, 2>(a, p, stream);
+            case 3: return launch_wino_hw<8, 3, true, 3>(a, p, stream);
+            case 8: return launch_wino_hw<8, 3, true, 8>(a, p, stream);
+            case 16: return launch_wino_hw<8, 3, true, 16>(a, p, stream);
+            case 32: return launch_wino_hw<8, 3, true, 32>(a, p, stream);
+            case 48: return launch_wino_hw<8, 3, true, 48>(a, p, stream);
+            default: break;
+          }
+#endif
+          return launch_wino_hw<8, 3, true>(a, p, stream);
+        }
       }
       return p.plane <= 384 ? launch_wino_hw<8, 6>(a, p, stream) : launch_wino_hw<8, 10>(a, p, stream);
     }

@@ -251,7 +251,7 @@ def test_graphed_query_encoder_matches_eager(split, monkeypatch):
                                                            for i in range(1, 6)]
             for m in mods:
                 ents = list(m.__dict__["_coclr_graph_entries"].values())
-                assert any(e.fwd is not None and e.bwd is not None for e in ents), \\
+                assert any(e.fwd is not None and e.bwd is not None for e in ents), \
                     "the pass was never captured"
         results.append((outs, [p.detach().clone() for p in model.parameters()],
                         {k: v.clone() for k, v in model.state_dict().items()}))
