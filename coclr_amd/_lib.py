@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "coclr_queue_fill_i64": [vp, vp, i64, i32, i32, vp, vp],
     "coclr_queue_advance": [vp, i32, i32, vp],
     "coclr_positive_mask": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "coclr_mine_positives": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "coclr_gather_rows": [vp, vp, vp, i32, i64, i64, vp],
     "coclr_pull_rows": [vp, vp, i32, i64, vp],
     "coclr_relu_fwd": [vp, vp, i64, vp],

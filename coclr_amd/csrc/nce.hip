@@ -346,6 +346,164 @@ positive_mask_kernel(const float* __restrict__ sim, const int64_t* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// CoCLR positive mining (model/pretrain.py:397-413) as ONE launch with no (B, K) similarity
+// tensor: sim = kf @ queue_second on the MFMA pipe, tile by tile, with a running top-k.
+//   * a workgroup owns 32 rows x 64 queue columns: the queue tile goes straight into MFMA operand
+//     registers, the four waves split the 128 feature channels and meet through LDS (the layout of
+//     nce_logits_kernel);
+//   * it writes the same-source ("sibling") bits of its columns into the mask and, per row, its
+//     `topk` best non-sibling columns (value desc, column asc) into a candidate table;
+//   * the LAST workgroup of a row tile to finish (one device-scope counter per row tile, reset by its
+//     last user) merges the K/64 x topk candidates of each of its rows and sets the winners' bits.
+// -inf entries need no candidates: the only -inf columns are siblings, whose bits are set anyway
+// (torch.topk falls back to them, lowest index first, when fewer than topk finite values remain).
+// ---------------------------------------------------------------------------
+struct MineBest { float v; int i; };
+
+__device__ __forceinline__ bool mine_better(float v, int i, float bv, int bi) {
+  return v > bv || (v == bv && i < bi);
+}
+
+template <int D>
+__global__ void __launch_bounds__(256)
+mine_positives_kernel(const float* __restrict__ kf, const float* __restrict__ queue2,
+                      const int64_t* __restrict__ src, const int64_t* __restrict__ names,
+                      uint8_t* __restrict__ mask, float* cand_val, int* cand_idx, int* counters,
+                      float* __restrict__ sim_out, int B, int K, int topk) {
+  constexpr int NT = 64, DW = D / 4, STEPS = DW / 2, LDQ = D + 1;
+  __shared__ float qs[32 * LDQ];
+  __shared__ float part[4][32][NT + 1];
+  __shared__ int last_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntiles = gridDim.x;
+  const int n0 = blockIdx.x * NT, m0 = blockIdx.y * 32;
+
+  const int d0 = wave * DW;
+  float bv[2][STEPS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = n0 + t * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+      bv[t][s] = col < K ? queue2[(long)(d0 + 2 * s + half) * K + col] : 0.f;
+  }
+  {
+    float4 qv[32 * D / 4 / 256];
+#pragma unroll
+    for (int i = 0; i < 32 * D / 4 / 256; ++i) {
+      const int e = tid + i * 256;
+      const int r = e / (D / 4), c4 = e - r * (D / 4);
+      qv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + r < B) qv[i] = reinterpret_cast<const float4*>(kf + (long)(m0 + r) * D)[c4];
+    }
+#pragma unroll
+    for (int i = 0; i < 32 * D / 4 / 256; ++i) {
+      const int e = tid + i * 256;
+      const int r = e / (D / 4), c4 = e - r * (D / 4);
+      float* d = &qs[r * LDQ + c4 * 4];
+      d[0] = qv[i].x; d[1] = qv[i].y; d[2] = qv[i].z; d[3] = qv[i].w;
+    }
+  }
+  __syncthreads();
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const float av = qs[l31 * LDQ + d0 + 2 * s + half];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[0][s], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[1][s], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = (i & 3) + 8 * (i >> 2) + 4 * half;
+    part[wave][r][l31] = acc0[i];
+    part[wave][r][32 + l31] = acc1[i];
+  }
+  __syncthreads();
+  // thread = (row r, octet o): 8 columns of the row; siblings -> mask bit and -inf
+  const int r = tid >> 3, o = tid & 7;
+  const int row = m0 + r;
+  const bool rok = row < B;
+  const int64_t s_row = rok ? src[row] : 0;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = o * 8 + j, col = n0 + c;
+    float x = (part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c]);
+    bool same = false;
+    if (rok && col < K) {
+      same = names[col] == s_row;
+      mask[(long)row * (1 + K) + 1 + col] = same ? 1 : 0;
+      if (sim_out) sim_out[(long)row * K + col] = x;
+    }
+    v[j] = (rok && col < K && !same) ? x : -INFINITY;
+  }
+  if (blockIdx.x == 0 && o == 0 && rok) mask[(long)row * (1 + K)] = 1;
+  // the row's topk best of this tile: repeated arg-max over the 8 lanes of the row
+  for (int t = 0; t < topk; ++t) {
+    MineBest b = {-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (mine_better(v[j], n0 + o * 8 + j, b.v, b.i)) { b.v = v[j]; b.i = n0 + o * 8 + j; }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      const float ov = __shfl_xor(b.v, off);
+      const int oi = __shfl_xor(b.i, off);
+      if (mine_better(ov, oi, b.v, b.i)) { b.v = ov; b.i = oi; }
+    }
+    if (b.v == -INFINITY) b.i = -1;                     // nothing (finite) left in this tile
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (n0 + o * 8 + j == b.i) v[j] = -INFINITY;       // taken
+    if (o == 0 && rok) {
+      const long slot = ((long)row * ntiles + blockIdx.x) * topk + t;
+      cand_val[slot] = b.v;
+      cand_idx[slot] = b.i;
+    }
+  }
+  // ---- who is last for this row tile? -------------------------------------------------------
+  __threadfence();                                        // candidates + mask bytes visible device-wide
+  __syncthreads();
+  if (tid == 0) {
+    const int prev = atomicAdd(&counters[blockIdx.y], 1);
+    last_flag = prev == ntiles - 1;
+    if (last_flag) counters[blockIdx.y] = 0;              // ready for the next launch
+  }
+  __syncthreads();
+  if (!last_flag || topk == 0) return;
+  __threadfence();
+  // ---- merge: the row's 8 lanes scan ntiles*topk candidates, topk rounds --------------------
+  if (!rok) return;
+  const int ncand = ntiles * topk;
+  const float* cv = cand_val + (long)row * ncand;
+  const int* ci = cand_idx + (long)row * ncand;
+  float last_v = INFINITY;
+  int last_i = -1;
+  for (int t = 0; t < topk; ++t) {
+    // best candidate strictly after the previous pick in (value desc, column asc) order
+    MineBest b = {-INFINITY, 0x7fffffff};
+    for (int e = o; e < ncand; e += 8) {
+      const float x = __builtin_nontemporal_load(&cv[e]);
+      const int i = __builtin_nontemporal_load(&ci[e]);
+      if (i < 0) continue;
+      const bool after = x < last_v || (x == last_v && i > last_i);
+      if (after && mine_better(x, i, b.v, b.i)) { b.v = x; b.i = i; }
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      const float ov = __shfl_xor(b.v, off);
+      const int oi = __shfl_xor(b.i, off);
+      if (mine_better(ov, oi, b.v, b.i)) { b.v = ov; b.i = oi; }
+    }
+    if (b.i == 0x7fffffff) break;                         // fewer than topk non-sibling columns
+    if (o == 0) mask[(long)row * (1 + K) + 1 + b.i] = 1;
+    last_v = b.v; last_i = b.i;
+  }
+}
+
 // out[i][:] = in[idx[i]][:]   (rows of `row_elems` floats)
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, float* out,
@@ -536,6 +694,20 @@ extern "C" int coclr_positive_mask(const float* sim, const int64_t* src, const i
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(positive_mask_kernel), 150 * 1024, attr_done));
   hipLaunchKernelGGL(positive_mask_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sim, src,
                      names, mask, K, topk);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_mine_positives(const float* kf, const float* queue_second, const int64_t* src,
+                                    const int64_t* names, uint8_t* mask, float* cand_val,
+                                    int32_t* cand_idx, int32_t* counters, float* sim_out, int B,
+                                    int D, int K, int topk, void* stream) {
+  if (!kf || !queue_second || !src || !names || !mask || !counters) return COCLR_EINVAL;
+  if (B <= 0 || K <= 0 || D != 128 || topk < 0 || topk > 16 || topk > K) return COCLR_EINVAL;
+  if (topk > 0 && (!cand_val || !cand_idx)) return COCLR_EINVAL;
+  hipLaunchKernelGGL(mine_positives_kernel<128>, dim3(cdiv(K, 64), cdiv(B, 32)), dim3(256), 0,
+                     (hipStream_t)stream, kf, queue_second, src, names, mask, cand_val, cand_idx,
+                     counters, sim_out, B, K, topk);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

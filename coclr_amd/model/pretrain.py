@@ -896,10 +896,19 @@ class CoCLR(InfoNCE):
         if self.queue_is_full and (self.topk != 0):
             # cross-modal similarity against the second queue, top-k mined per row with
             # same-source (sibling) entries excluded (ref :405-410)
-            sim = torch.empty(B, self.K, dtype=kf.dtype, device=kf.device)
-            ops.gemm(kf, self.dim, 1, self.queue_second, self.K, 1, sim, self.K, None, B, self.K,
-                     self.dim)
-            ops.positive_mask(sim, k_vsource, self.queue_vname, mask, int(self.topk))
+            if self.dim == 128 and 0 < int(self.topk) <= 16:
+                # similarity tiles on the MFMA pipe with a running top-k: one launch, no (B, K) tensor
+                ws = self.__dict__.get("_mine_ws")
+                if ws is None or ws[3] != (B, self.K, int(self.topk), kf.device):
+                    ws = self.__dict__["_mine_ws"] = ops.mine_workspace(
+                        B, self.K, int(self.topk), kf.device) + ((B, self.K, int(self.topk), kf.device),)
+                ops.mine_positives(kf.contiguous(), self.queue_second, k_vsource, self.queue_vname,
+                                   mask, int(self.topk), ws[:3])
+            else:
+                sim = torch.empty(B, self.K, dtype=kf.dtype, device=kf.device)
+                ops.gemm(kf, self.dim, 1, self.queue_second, self.K, 1, sim, self.K, None, B, self.K,
+                         self.dim)
+                ops.positive_mask(sim, k_vsource, self.queue_vname, mask, int(self.topk))
         else:
             ops.positive_mask(None, k_vsource, self.queue_vname, mask, 0)
 

@@ -497,6 +497,30 @@ def positive_mask(sim, src, names, mask, topk):
         topk, _stream()), "positive_mask")
 
 
+def mine_workspace(B, K, topk, device):
+    """(candidate values, candidate columns, zeroed row-tile counters) for mine_positives; the
+    counters are left zero by every launch, so one workspace serves a model for its lifetime."""
+    nt = (K + 63) // 64
+    return (torch.empty(B * nt * max(topk, 1), dtype=torch.float32, device=device),
+            torch.empty(B * nt * max(topk, 1), dtype=torch.int32, device=device),
+            torch.zeros((B + 31) // 32, dtype=torch.int32, device=device))
+
+
+def mine_positives(kf, queue_second, src, names, mask, topk, workspace, sim_out=None):
+    """mask <- column 0 | same-source columns | top-k of kf @ queue_second over the other columns, in
+    one launch (model/pretrain.py:397-413)."""
+    B, D = kf.shape
+    K = queue_second.shape[1]
+    cv, ci, cnt = workspace
+    nt = (K + 63) // 64
+    if cv.numel() < B * nt * max(topk, 1) or cnt.numel() < (B + 31) // 32:
+        raise ValueError("coclr_amd: mine_positives workspace too small")
+    _lib.check(_L().coclr_mine_positives(
+        _p(kf), _p(queue_second), _p(src, torch.int64), _p(names, torch.int64), _p(mask, torch.uint8),
+        _p(cv), _p(ci, torch.int32), _p(cnt, torch.int32), _p(sim_out), B, D, K, topk, _stream()),
+        "mine_positives")
+
+
 def gather_rows(inp, idx, out):
     """out[i] = inp[idx[i]]; `inp` rows must be dense but may be strided along dim 0."""
     rows = out.shape[0]

@@ -254,6 +254,17 @@ int coclr_queue_advance(int64_t* ptr, int BW, int K, void* stream);
 int coclr_positive_mask(const float* sim, const int64_t* src, const int64_t* names, uint8_t* mask,
                         int B, int K, int topk, void* stream);
 
+/* The same mask with the similarity product folded in and no (B, K) similarity tensor
+ * (pretrain.py:405-410: `sim = kf.matmul(queue_second)`, siblings to -inf, topk, scatter): ONE launch,
+ * sim tiles on the MFMA pipe, a running top-k per row across tiles.  kf [B][D] unit rows, queue_second
+ * [D][K]; D must be 128, topk <= 16.  Workspaces: cand_val / cand_idx [B][ceil(K/64)][topk];
+ * counters [ceil(B/32)] int32, ZERO before the first call (every call leaves them zero again).
+ * sim_out (optional, [B][K]) receives the similarities, for tests. */
+int coclr_mine_positives(const float* kf, const float* queue_second, const int64_t* src,
+                         const int64_t* names, uint8_t* mask, float* cand_val, int32_t* cand_idx,
+                         int32_t* counters, float* sim_out, int B, int D, int K, int topk,
+                         void* stream);
+
 /* out[i][:] = in[idx[i]][:] (pretrain.py:124,143); rows of `row_elems` floats, source rows
  * `in_row_stride` floats apart (>= row_elems: the second clip of a (B,2,...) pair is a
  * strided view). */

@@ -216,12 +216,16 @@ PRETRAIN_SEEDS = {"rgb": 501, "flow": 502}
 def write_pretrained_pair(directory, use_reference_model, product=None):
     """rgb.pth.tar / flow.pth.tar for `main_coclr.py --pretrain`, from the reference's InfoNCE (fixture
     generation) or the product's (tests): same names, shapes and values either way."""
-    if product is None:
-        with script_environment(use_reference_model, cpu=True):
-            import model.pretrain as product_mod
-            model = product_mod.InfoNCE("s3d", 128, 8, 0.999, 0.07)
-    else:
-        model = product.InfoNCE("s3d", 128, 8, 0.999, 0.07)
+    # the model is built under its own seed (global RNG state restored afterwards): the parameters the
+    # re-draw below leaves alone -- the projection head's biases -- must not depend on what ran before
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(4242)
+        if product is None:
+            with script_environment(use_reference_model, cpu=True):
+                import model.pretrain as product_mod
+                model = product_mod.InfoNCE("s3d", 128, 8, 0.999, 0.07)
+        else:
+            model = product.InfoNCE("s3d", 128, 8, 0.999, 0.07)
     for tag, seed in PRETRAIN_SEEDS.items():
         write_pretrained(os.path.join(directory, tag + ".pth.tar"), model, seed)
 

@@ -325,6 +325,17 @@ def positive_mask(sim, src, names, mask, topk):
     mask[:, 1:] = m.to(mask.dtype)
 
 
+def mine_workspace(B, K, topk, device):
+    return (torch.empty(1), torch.empty(1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))
+
+
+def mine_positives(kf, queue_second, src, names, mask, topk, workspace, sim_out=None):
+    sim = kf.matmul(queue_second)
+    if sim_out is not None:
+        sim_out.copy_(sim)
+    positive_mask(sim, src, names, mask, topk)
+
+
 def gather_rows(inp, idx, out):
     out.copy_(inp[idx])
 

@@ -261,6 +261,32 @@ def test_cross_modal_mining_at_config_sizes(K):
     exp.scatter_(1, idx, True)
     exp = torch.cat([torch.ones(B, 1, dtype=torch.bool), exp], 1)
     assert torch.equal(got, exp)
+    # the fused form (coclr_mine_positives: similarity tiles + running top-k, one launch, no sim
+    # tensor): same mask; its similarities (optional debug output) equal the GEMM's to round-off
+    ws = ops.mine_workspace(B, K, topk, "cuda")
+    sim2 = torch.empty(B, K, device="cuda")
+    for rep in range(2):                               # twice: the counters must come back to zero
+        mask2 = torch.full((B, 1 + K), 7, dtype=torch.uint8, device="cuda")
+        ops.mine_positives(kf.cuda(), queue2.cuda(), src.cuda(), names.cuda(), mask2, topk, ws, sim_out=sim2)
+        s2 = sim2.cpu()
+        assert float((s2 - sim_ref).abs().max() / sim_ref.abs().max()) <= 2e-5
+        ms2 = s2.clone()
+        ms2[same_k] = -float("inf")
+        _, idx2 = torch.topk(ms2, topk, dim=1)
+        exp2 = same_k.clone()
+        exp2.scatter_(1, idx2, True)
+        exp2 = torch.cat([torch.ones(B, 1, dtype=torch.bool), exp2], 1)
+        assert torch.equal(mask2.cpu().bool(), exp2), "fused mining, pass %d" % rep
+        assert int(ws[2].abs().sum()) == 0
+    # fused form on rows with fewer than topk (3) and no (0) non-sibling columns: siblings only + the 3
+    for nfree in (3, 0):
+        nm = src[:1].repeat(K)
+        free = torch.tensor([5, K // 2, K - 1])[:nfree]
+        nm[free] = -5
+        m1 = torch.empty(1, 1 + K, dtype=torch.uint8, device="cuda")
+        ops.mine_positives(kf[:1].cuda(), queue2.cuda(), src[:1].cuda(), nm.cuda(), m1, topk,
+                           ops.mine_workspace(1, K, topk, "cuda"))
+        assert int(m1.sum()) == 1 + K, "every column is a sibling or one of the %d free ones" % nfree
     # rows with fewer than topk finite candidates, through single-row launches with their own
     # name tables: 3 free columns -> exactly those 3 plus two -inf picks (torch.topk takes the
     # lowest-index -inf entries; so does the kernel), 0 free columns -> the siblings only plus
