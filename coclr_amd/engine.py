@@ -942,6 +942,10 @@ def _graph_entry(module, x, params, kwargs):
     key = (tuple(x.shape), bool(x.requires_grad))
     ent = store.get(key)
     if ent is None or ent.sig != sig:
+        if ent is not None:                      # its static buffers go away with it
+            for t in (ent.out, ent.dx):
+                if t is not None:
+                    _STATIC_PTRS.discard(t.data_ptr())
         ent = store[key] = _GraphEntry(sig)      # new shape / moved storage / flags changed: start over
     if ent.disabled:
         return None
@@ -949,7 +953,15 @@ def _graph_entry(module, x, params, kwargs):
     if ent.seen <= _GRAPH_WARMUP:
         return None
     if ent.fwd is None:
-        _capture_forward(module, x, params, ent)
+        try:
+            _capture_forward(module, x, params, ent)
+        except (RuntimeError, ValueError) as e:
+            # e.g. an input whose rows are not dense: this (module, shape) stays on the eager path
+            ent.disabled = True
+            import warnings
+            warnings.warn("coclr_amd: hipGraph capture of %s failed (%s); running it eagerly"
+                          % (type(module).__name__, e))
+            return None
     return ent
 
 
