@@ -427,8 +427,8 @@ conv_igemm_kernel(const ConvArgs a) {
 // the B operand of virtual tap i is a difference or sum of two window rows (one VALU op), that a
 // wave keeps four accumulators per 32x32 block, and that the epilogue emits two frames.
 // 1.5x fewer MFMAs for the (3,1,1) layers (27 % of the S3D conv FLOPs), forward and dgrad.
-template <int CC, int BM, int BNP, int PCH, bool XV4>
-__global__ void __launch_bounds__(256)
+template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC)
 conv_wino_t_kernel(const ConvArgs a) {
   constexpr int TAPS = 4;
   constexpr int WM = 2, WN = 2;
@@ -714,7 +714,7 @@ conv_wino_t_kernel(const ConvArgs a) {
   }
 }
 
-template <int CC, int BM, int BNP, int PCH, bool XV4>
+template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC = 1>
 int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   if (p.plane > PCH * 64) return COCLR_EINVAL;
   a.mtiles = cdiv(a.Cout, BM);
@@ -726,7 +726,7 @@ int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_wino_t_kernel<CC, BM, BNP, PCH, XV4>;
+  auto kern = conv_wino_t_kernel<CC, BM, BNP, PCH, XV4, OCC>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   hipLaunchKernelGGL(kern, dim3((unsigned)((long)a.mtiles * a.ntiles)), dim3(256), lds, stream, a);
@@ -1945,9 +1945,14 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
   switch (variant) {
     case 0:  return xv4 ? launch_variant<1, 1, 1, 32, 128, 128, 2, true>(a, p, stream)
                         : launch_variant<1, 1, 1, 32, 128, 128, 2>(a, p, stream);
-    case 1:  return xv4 ? launch_variant<1, 1, 1, 32, 64, 128, 2, true>(a, p, stream)
+    // 16-byte-staged kernels run with HALF the channel chunk of their 4-byte forms: the chunk is what
+    // sizes the LDS stages, and two or three workgroups per CU became five or six.  Measured at B=32
+    // (same box, alternating): Conv_2b 0.082 -> 0.070 ms forward / 0.070 -> 0.059 data gradient, the
+    // fused heads of Mixed_3c 0.223 -> 0.20 / 0.19 -> 0.195, of Mixed_4b 0.058 -> 0.054 / 0.060 ->
+    // 0.051, Conv_1a.conv2 1.36 -> 1.31; the (1,3,3) small-map kernel did not move and keeps 8.
+    case 1:  return xv4 ? launch_variant<1, 1, 1, 16, 64, 128, 2, true>(a, p, stream)
                         : launch_variant<1, 1, 1, 32, 64, 128, 2>(a, p, stream);
-    case 2:  return xv4 ? launch_variant<1, 1, 1, 32, 64, 64, 1, true>(a, p, stream)
+    case 2:  return xv4 ? launch_variant<1, 1, 1, 16, 64, 64, 1, true>(a, p, stream)
                         : launch_variant<1, 1, 1, 32, 64, 64, 1>(a, p, stream);
     case 3:  return launch_variant<1, 1, 1, 16, 64, 64, 4>(a, p, stream);
     case 10: return xg ? launch_variant<1, 3, 3, 4, 128, 128, 3, false, true>(a, p, stream)
@@ -1974,8 +1979,12 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
       const bool xv4 = p.Hi == 1 && p.WH == 1 && p.lTW >= 2 && (p.Wi % 4) == 0 &&
                        (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 &&
                        (p.plane % 4) == 0;
-      return xv4 ? launch_wino_t<16, 64, 64, 4, true>(a, p, stream)
-                 : launch_wino_t<16, 64, 64, 4, false>(a, p, stream);
+      // 8-channel chunks and a four-workgroups-per-CU register budget (accumulators in arch VGPRs,
+      // 99 registers; 27 KB of LDS): four waves per SIMD instead of three.  Measured at B=32 against
+      // the 16-channel / three-wave form: Conv_2c.conv2 1.02-1.06 -> 0.99 ms forward, 0.907 -> 0.874
+      // data gradient; Mixed_3c.b1.conv2 0.212 -> 0.204 / 0.205 -> 0.200; the 8x8x8 layers unchanged.
+      if (xv4) return launch_wino_t<8, 64, 64, 4, true, 4>(a, p, stream);
+      return launch_wino_t<16, 64, 64, 4, false>(a, p, stream);
     }
     case 60: {
       // a.Ho/Wo = 2x2 blocks; the destination keeps its full row pitch
@@ -2017,7 +2026,7 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
     }
     case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);
     case 31: return launch_stem<7, 7, 3, 20>(a, p, stream);
-    case 40: return xv4 ? launch_variant<7, 1, 1, 8, 64, 128, 8, true>(a, p, stream)
+    case 40: return xv4 ? launch_variant<7, 1, 1, 4, 64, 128, 8, true>(a, p, stream)
                         : launch_variant<7, 1, 1, 8, 64, 128, 8>(a, p, stream);
   }
   return COCLR_EINVAL;

@@ -34,6 +34,8 @@ L = [("Conv_1a.conv1", 3, 64, (1,7,7), (1,2,2), (0,3,3), (32,128,128)),
      ("3c.b0", 256, 128, (1,1,1), (1,1,1), (0,0,0), (16,16,16)),
      ("4b.b0", 480, 192, (1,1,1), (1,1,1), (0,0,0), (8,8,8)),
      ("4f.b1.conv1", 160, 320, (1,3,3), (1,1,1), (0,1,1), (8,8,8)),
+     ("3c.group", 256, 288, (1,1,1), (1,1,1), (0,0,0), (16,16,16)),
+     ("4b.group", 480, 304, (1,1,1), (1,1,1), (0,0,0), (8,8,8)),
      ("4b.b2.conv1", 16, 48, (1,3,3), (1,1,1), (0,1,1), (8,8,8)),
      ("4c.b1.conv1", 112, 224, (1,3,3), (1,1,1), (0,1,1), (8,8,8)),
      ("4f.b1.conv2", 320, 320, (3,1,1), (1,1,1), (1,0,0), (8,8,8)),
