@@ -241,18 +241,54 @@ class S3D(_Emitter):
             x = blk._emit(run, x)
         return x
 
+    def _stage_groups(self):
+        """Autograd-node partition used when the backbone runs as several nodes: the reference's
+        block1..block5 with every stage's LEADING max-pool moved to the end of the stage before it.
+        The pool that follows Conv_1a / Conv_2c then sits in the same engine run as the unit it
+        consumes and applies that unit's BatchNorm + ReLU while it reads (engine.max_pool, lazy apply)
+        -- a node boundary between them would force the 1 GB / 0.4 GB apply pass back in.  Plain
+        objects, not registered modules: the state dict keeps the reference's keys."""
+        groups = self.__dict__.get("_coclr_groups")
+        if groups is None:
+            b2, b3, b4, b5 = list(self.block2), list(self.block3), list(self.block4), list(self.block5)
+            groups = self.__dict__["_coclr_groups"] = [
+                _Group(list(self.block1) + b2[:1]), _Group(b2[1:] + b3[:1]), _Group(b3[1:] + b4[:1]),
+                _Group(b4[1:] + b5[:1]), _Group(b5[1:])]
+        return groups
+
     def forward(self, x, n_index=None):
-        """One autograd node per stage (block1..block5), like the reference's forward
-        (backbone/s3dg.py:211-217).  With gradients enabled this lets the gradients of the late
-        stages -- 216 of the 231 backbone tensors live in block3-5 -- reach DistributedDataParallel
-        while the early stages are still in backward: its per-parameter bucket copies and the
-        all-reduce then overlap the weight-gradient stream instead of forming a host-paced tail
-        after the whole backward."""
+        """One autograd node per stage, like the reference's forward (backbone/s3dg.py:211-217).  With
+        gradients enabled this lets the gradients of the late stages -- 216 of the 231 backbone tensors
+        live in block3-5 -- reach DistributedDataParallel while the early stages are still in
+        backward: its bucket all-reduce then overlaps the weight-gradient stream instead of forming a
+        tail after the whole backward."""
         if not (torch.is_grad_enabled() and _split_stages()):
             return engine.run_module(self, x, n_index=n_index) if n_index is not None \
                 else engine.run_module(self, x)
-        x = engine.run_module(self.block1, x, n_index=n_index) if n_index is not None \
-            else engine.run_module(self.block1, x)
-        for blk in (self.block2, self.block3, self.block4, self.block5):
-            x = engine.run_module(blk, x)
+        groups = self._stage_groups()
+        x = engine.run_module(groups[0], x, n_index=n_index) if n_index is not None \
+            else engine.run_module(groups[0], x)
+        for grp in groups[1:]:
+            x = engine.run_module(grp, x)
+        return x
+
+
+class _Group:
+    """A run of backbone modules executed as ONE engine run / autograd node (see S3D._stage_groups).
+    Not an nn.Module: nothing is registered, `parameters()` is what engine.run_module needs."""
+
+    def __init__(self, mods):
+        self.mods = mods
+
+    def parameters(self):
+        for m in self.mods:
+            yield from m.parameters()
+
+    def modules(self):
+        for m in self.mods:
+            yield from m.modules()
+
+    def _emit(self, run, x, n_index=None):
+        for i, m in enumerate(self.mods):
+            x = m._emit(run, x, n_index=n_index) if (i == 0 and n_index is not None) else m._emit(run, x)
         return x

@@ -247,8 +247,7 @@ def test_graphed_query_encoder_matches_eager(split, monkeypatch):
             outs.append(out.detach().clone())
         torch.cuda.synchronize()
         if graphed:
-            mods = [model.encoder_q[0]] if not split else [getattr(model.encoder_q[0], "block%d" % i)
-                                                           for i in range(1, 6)]
+            mods = [model.encoder_q[0]] if not split else model.encoder_q[0]._stage_groups()
             for m in mods:
                 ents = list(m.__dict__["_coclr_graph_entries"].values())
                 assert any(e.fwd is not None and e.bwd is not None for e in ents), \
