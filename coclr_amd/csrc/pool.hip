@@ -361,6 +361,150 @@ maxpool333_kernel(const float* __restrict__ x, float* __restrict__ y, int* __res
   }
 }
 
+// ---------------------------------------------------------------------------
+// BatchNorm(+ReLU) backward of a unit whose ONLY consumer is a max-pool that applied the affine +
+// ReLU while reading (engine.max_pool, lazy apply: MaxPool_2a behind Conv_1a, MaxPool_3a behind
+// Conv_2c).  The gradient dz of the normalised activation is then nothing but the pool's dy scattered
+// to the arg-max positions, so it is never materialised:
+//   reduce (output-centric): sum g and sum g*xhat over the pool OUTPUTS, g = dy_pool[o] masked by the
+//           ReLU at y[argmax(o)]  -- reads the two quarter-size tensors and gathers y;
+//   apply  (the pool-backward tile kernel with a BatchNorm epilogue): the plane's g in LDS (colour
+//           classes, deterministic), then dy_bn = A*g*mask + B*y + D streamed out with y streamed in.
+// Against pool backward + two-pass BatchNorm backward (6.5 |y| of traffic, three kernels) this moves
+// about 4 |y| in two.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+bn_pool_bwd_reduce_kernel(const float* __restrict__ pdy, const int* __restrict__ pidx,
+                          const float* __restrict__ y, const float* __restrict__ scale,
+                          const float* __restrict__ shift, const float* __restrict__ mean,
+                          const float* __restrict__ invstd, double* sums, int C, int So, int Si,
+                          long pdy_nstride, long y_nstride, int relu) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, n = blockIdx.y;
+  const float sc = scale[c], sf = shift[c], mu = mean[c], is = invstd[c];
+  const float* dp = pdy + (long)n * pdy_nstride + (long)c * So;
+  const int* ip = pidx + ((long)n * C + c) * So;
+  const float* yp = y + (long)n * y_nstride + (long)c * Si;
+  float ag = 0.f, agx = 0.f;
+  for (int o = threadIdx.x; o < So; o += 256) {
+    float g = dp[o];
+    const float v = yp[ip[o]];
+    if (relu) g = fmaf(v, sc, sf) > 0.f ? g : 0.f;
+    ag += g;
+    agx += g * ((v - mu) * is);
+  }
+  double sg = block256_sum_d((double)ag, red);
+  double sgx = block256_sum_d((double)agx, red);
+  if (threadIdx.x == 0) {
+    sums[((long)c * gridDim.y + n) * 2] = sg;
+    sums[((long)c * gridDim.y + n) * 2 + 1] = sgx;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_pool_bwd_apply_kernel(const float* __restrict__ pdy, const int* __restrict__ pidx,
+                         const float* __restrict__ y, const float* __restrict__ scale,
+                         const float* __restrict__ shift, const float* __restrict__ mean,
+                         const float* __restrict__ invstd, const double* __restrict__ sums, int groups,
+                         double count, int training, float* dgamma, float* dbeta, float* dy,
+                         const PoolGeom g, long pdy_nstride, long y_nstride, long dy_nstride, int relu,
+                         int G, int planes, int tfold) {
+  extern __shared__ float tile[];   // [G][Si]
+  __shared__ double tot[2];
+  __shared__ float coef[8][4];      // per volume of the group: A, B, D, (unused)
+  const int Si = g.Ti * g.Hi * g.Wi, So = g.To * g.Ho * g.Wo;
+  const int pl0 = blockIdx.x * G;
+  const int gcount = min(G, planes - pl0);
+  for (int i = threadIdx.x; i < gcount * Si; i += 256) tile[i] = 0.f;
+  // coefficients of the channels this group touches (g.C counts folded planes: channel = (pl % C) / tfold)
+  for (int gi = 0; gi < gcount; ++gi) {
+    const int pl = pl0 + gi;
+    const int c = (pl % g.C) / tfold;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double a0 = 0.0, a1 = 0.0;
+      for (int k = threadIdx.x; k < groups; k += 64) {
+        a0 += sums[((long)c * groups + k) * 2];
+        a1 += sums[((long)c * groups + k) * 2 + 1];
+      }
+      a0 = wave_sum_d(a0);
+      a1 = wave_sum_d(a1);
+      if (threadIdx.x == 0) { tot[0] = a0; tot[1] = a1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double sg = tot[0], sgx = tot[1];
+      const float sc = scale[c];
+      float A = sc, B = 0.f, D = 0.f;
+      if (training) {
+        const float mg = (float)(sg / count), mgx = (float)(sgx / count);
+        B = -sc * invstd[c] * mgx;
+        D = sc * (mean[c] * invstd[c] * mgx - mg);
+      }
+      coef[gi][0] = A; coef[gi][1] = B; coef[gi][2] = D;
+      // the plane (sample 0, frame 0) of a channel also emits its dgamma / dbeta
+      if (pl / g.C == 0 && (pl % g.C) % tfold == 0) {
+        if (dgamma) dgamma[c] = (float)sgx;
+        if (dbeta) dbeta[c] = (float)sg;
+      }
+    }
+  }
+  const int Pt = (g.kt + g.st - 1) / g.st, Ph = (g.kh + g.sh - 1) / g.sh, Pw = (g.kw + g.sw - 1) / g.sw;
+  for (int ct = 0; ct < Pt; ++ct)
+    for (int ch = 0; ch < Ph; ++ch)
+      for (int cw = 0; cw < Pw; ++cw) {
+        __syncthreads();
+        const int nt = (g.To - ct + Pt - 1) / Pt, nh = (g.Ho - ch + Ph - 1) / Ph,
+                  nw = (g.Wo - cw + Pw - 1) / Pw;
+        if (nt <= 0 || nh <= 0 || nw <= 0) continue;
+        const int csize = nt * nh * nw;
+        for (int q = threadIdx.x; q < gcount * csize; q += 256) {
+          const int gi = q / csize;
+          int m = q - gi * csize;
+          const int a = m / (nh * nw);
+          m -= a * nh * nw;
+          const int b = m / nw, cc = m - b * nw;
+          const int o = ((a * Pt + ct) * g.Ho + (b * Ph + ch)) * g.Wo + (cc * Pw + cw);
+          const int pl = pl0 + gi;
+          const int n = pl / g.C, c = pl - n * g.C;
+          const int i = pidx[(long)pl * So + o] - (pl % tfold) * Si;
+          tile[gi * Si + i] += pdy[(long)n * pdy_nstride + (long)c * So + o];
+        }
+      }
+  __syncthreads();
+  for (int gi = 0; gi < gcount; ++gi) {
+    const int pl = pl0 + gi;
+    const int n = pl / g.C, c = pl - n * g.C;       // c: folded plane index inside the sample
+    const int ch = c / tfold;
+    const float A = coef[gi][0], B = coef[gi][1], D = coef[gi][2];
+    const float sc = scale[ch], sf = shift[ch];
+    const float* yp = y + (long)n * y_nstride + (long)c * Si;
+    float* dyp = dy + (long)n * dy_nstride + (long)c * Si;
+    const float* tp = tile + gi * Si;
+    if ((Si & 3) == 0 && ((y_nstride | dy_nstride) & 3) == 0) {
+      for (int i = threadIdx.x; i < (Si >> 2); i += 256) {
+        float4 gq = reinterpret_cast<const float4*>(tp)[i];
+        const float4 v = reinterpret_cast<const float4*>(yp)[i];
+        if (relu) {
+          gq.x = fmaf(v.x, sc, sf) > 0.f ? gq.x : 0.f; gq.y = fmaf(v.y, sc, sf) > 0.f ? gq.y : 0.f;
+          gq.z = fmaf(v.z, sc, sf) > 0.f ? gq.z : 0.f; gq.w = fmaf(v.w, sc, sf) > 0.f ? gq.w : 0.f;
+        }
+        float4 o;
+        o.x = fmaf(A, gq.x, fmaf(B, v.x, D)); o.y = fmaf(A, gq.y, fmaf(B, v.y, D));
+        o.z = fmaf(A, gq.z, fmaf(B, v.z, D)); o.w = fmaf(A, gq.w, fmaf(B, v.w, D));
+        reinterpret_cast<float4*>(dyp)[i] = o;
+      }
+    } else {
+      for (int i = threadIdx.x; i < Si; i += 256) {
+        float gv = tp[i];
+        const float v = yp[i];
+        if (relu) gv = fmaf(v, sc, sf) > 0.f ? gv : 0.f;
+        dyp[i] = fmaf(A, gv, fmaf(B, v, D));
+      }
+    }
+  }
+}
+
 // Backward of the 3x3x3 / stride 1 / pad 1 pool, GATHER form: dy and the argmax indices of G whole
 // volumes are staged in LDS, thread i sums dy[o] over the <= 27 outputs o whose window holds input i
 // and whose argmax is i, in fixed (t, h, w) order: no atomics, run-to-run deterministic, every
@@ -616,6 +760,41 @@ extern "C" int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, co
   hipLaunchKernelGGL(maxpool3d_bwd_kernel, pool_grid(g.N * g.C, g.Ti * g.Hi * g.Wi), dim3(256), 0,
                      (hipStream_t)stream, dy, indices, dx, g, (long)dy_nstride, (long)dx_nstride,
                      accumulate);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_bn_act_backward_pooled(const coclr_pool_desc* d, const float* pool_dy,
+                                            const int32_t* pool_idx, const float* y,
+                                            const float* scale, const float* shift,
+                                            const float* mean, const float* invstd, double* sums,
+                                            float* dy, float* dgamma, float* dbeta,
+                                            int64_t pool_dy_nstride, int64_t y_nstride,
+                                            int64_t dy_nstride, int relu, int training, void* stream) {
+  if (!d || d->N <= 0 || d->C <= 0 || !pool_dy || !pool_idx || !y || !sums || !dy) return COCLR_EINVAL;
+  const PoolGeom g0 = to_geom(d);
+  const PoolGeom g = fold_time(g0);
+  const int tfold = g.Ti == g0.Ti ? 1 : g0.Ti;
+  const int Si = g.Ti * g.Hi * g.Wi;
+  const int planes = g.N * g.C;
+  if (Si > kTileFloats) return COCLR_EINVAL;          // the caller falls back to the separate passes
+  int G = 4096 / Si > 0 ? 4096 / Si : 1;
+  if (G > 8) G = 8;
+  while (G > 1 && (planes + G - 1) / G < 1024) G >>= 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int So0 = g0.To * g0.Ho * g0.Wo, Si0 = g0.Ti * g0.Hi * g0.Wi;
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(g0.C, g0.N), dim3(256), 0, st, pool_dy, pool_idx,
+                     y, scale, shift, mean, invstd, sums, g0.C, So0, Si0, (long)pool_dy_nstride,
+                     (long)y_nstride, relu);
+  COCLR_LAUNCH_CHECK();
+  static std::atomic<uint64_t> done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(bn_pool_bwd_apply_kernel),
+                                 kTileFloats * 4, done));
+  const double count = (double)g0.N * Si0;
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3((planes + G - 1) / G), dim3(256),
+                     (size_t)G * Si * sizeof(float), st, pool_dy, pool_idx, y, scale, shift, mean, invstd,
+                     sums, g0.N, count, training, dgamma, dbeta, dy, g, (long)pool_dy_nstride,
+                     (long)y_nstride, (long)dy_nstride, relu, G, planes, tfold);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

@@ -240,6 +240,7 @@ class Run:
         # one backbone stage per collection (each stage's tape holds the previous stage's output,
         # whose grad_fn owns that stage's run) -- GBs of activations parked behind gc's schedule.
         self.tape = []
+        self.pooled = {}       # id(unit output) -> (pool geom, d(pool output), arg-max): see max_pool
         self.cur_lane = None
         self.lanes_on = False  # set per inception block (lanes_for)
         self._in_lane = False
@@ -606,16 +607,23 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
             raise NotImplementedError("coclr_amd: gathered conv input cannot require grad")
 
         def backward(run):
-            dz = run.grad_of(out)
             dy = torch.empty_like(y)
             dgb = (run.grad_out(bn.weight), run.grad_out(bn.bias))
             sums = run.empty(ops.bn_backward_workspace(N, Cout), dtype=torch.float64)
-            dres = None
-            dres_acc = False
-            if residual is not None and run.needs_grad(residual):
-                dres, dres_acc = run.grad_target(residual)
-            ops.bn_act_backward(dz, y, zv if residual is not None else None, scale, shift, mean,
-                                invstd, sums, dy, dres, dgb[0], dgb[1], relu, training, dres_acc)
+            pooled = run.pooled.pop(id(out.base), None)
+            if pooled is not None:
+                # the unit's only reader was a max-pool that applied BN+ReLU itself: its backward left
+                # (geometry, d(pool output), arg-max) here and d(activation) is never materialised
+                ops.bn_act_backward_pooled(pooled[0], pooled[1], pooled[2], y, scale, shift, mean,
+                                           invstd, sums, dy, dgb[0], dgb[1], relu, training)
+            else:
+                dz = run.grad_of(out)
+                dres = None
+                dres_acc = False
+                if residual is not None and run.needs_grad(residual):
+                    dres, dres_acc = run.grad_target(residual)
+                ops.bn_act_backward(dz, y, zv if residual is not None else None, scale, shift, mean,
+                                    invstd, sums, dy, dres, dgb[0], dgb[1], relu, training, dres_acc)
             if bn.weight.requires_grad:
                 run.add_param_grad(bn.weight, dgb[0])
             if bn.bias.requires_grad:
@@ -650,6 +658,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
 
 
 LAZY_APPLY = os.environ.get("COCLR_LAZY_APPLY", "1") != "0"
+POOLED_BACKWARD = os.environ.get("COCLR_POOLED_BACKWARD", "1") != "0"
 FUSE_POINTWISE = True     # debugging switch: False runs the units of a group one by one
 
 
@@ -754,17 +763,26 @@ def max_pool(run, x, kernel, stride, padding):
     y = run.empty(N, Cc, *g.odim)
     need = run.needs_grad(x)
     idx = run.empty(N, Cc, *g.odim, dtype=torch.int32) if need else None
+    fused = False
     if x.lazy is not None and x.whole:
         # BatchNorm + ReLU of the producing unit applied while the pool reads its raw output: the
         # normalised tensor is never written (its backward recomputes the ReLU mask from y)
         ysrc, scale, shift, relu = x.lazy
         x.lazy = "consumed"
         ops.maxpool_fwd(g, ysrc, y, idx, in_scale=scale, in_shift=shift, in_relu=relu)
+        # ... and nobody else can read it, so the unit's backward can take the pool's gradient in
+        # scattered form (conv_bn_act.backward -> ops.bn_act_backward_pooled)
+        fused = POOLED_BACKWARD and ops.pooled_backward_fits(g)
     else:
         ops.maxpool_fwd(g, x.view(), y, idx)
     out = Val(y)
     if need:
+        xid = id(x.base)
+
         def backward(run):
+            if fused:
+                run.pooled[xid] = (g, run.grad_of(out), idx)
+                return
             dx, acc = run.grad_target(x)
             ops.maxpool_bwd(g, run.grad_of(out), idx, dx, accumulate=acc)
         run.record(backward)

@@ -411,6 +411,29 @@ def maxpool_bwd(geom, dy, indices, dx, accumulate=False):
         _chk5(dx, "dx"), int(accumulate), _stream()), "maxpool3d_bwd")
 
 
+def bn_act_backward_pooled(geom, pool_dy, indices, y, scale, shift, mean, invstd, sums_ws, dy, dgamma,
+                           dbeta, relu, training):
+    """BatchNorm(+ReLU) backward of a unit consumed in fused form by the max-pool `geom`
+    (maxpool_fwd with in_scale / in_shift): pool backward, the two BatchNorm reductions and the
+    apply pass without ever writing the gradient of the normalised activation."""
+    N, C_ = y.shape[0], y.shape[1]
+    if sums_ws.numel() < 2 * C_ * N:
+        raise ValueError("coclr_amd: bn_act_backward_pooled workspace too small")
+    _lib.check(_L().coclr_bn_act_backward_pooled(
+        C.byref(_desc(geom)), _p(pool_dy), _p(indices, torch.int32), _p(y), _p(scale), _p(shift),
+        _p(mean), _p(invstd), _p(sums_ws, torch.float64), _p(dy), _p(dgamma), _p(dbeta),
+        _chk5(pool_dy, "pool_dy"), _chk5(y, "y"), _chk5(dy, "dy"), int(relu), int(training),
+        _stream()), "bn_act_backward_pooled")
+
+
+def pooled_backward_fits(geom):
+    """The fused form stages one (folded) input plane of the pool in LDS (csrc/pool.hip kTileFloats)."""
+    t, h, w = geom.idim
+    if geom.k[0] == 1 and geom.s[0] == 1 and geom.p[0] == 0:
+        t = 1
+    return t * h * w <= 16384
+
+
 def global_avgpool_fwd(x, y):
     planes = x.shape[0] * x.shape[1]
     _lib.check(_L().coclr_global_avgpool_fwd(_p(x), _p(y), planes, x.numel() // planes,

@@ -203,6 +203,21 @@ int coclr_maxpool3d_fwd(const coclr_pool_desc* d, const float* x, float* y, int3
 /* aten::max_pool3d_with_indices_backward, gather form (deterministic). */
 int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, const int32_t* indices, float* dx,
                         int64_t dy_nstride, int64_t dx_nstride, int accumulate, void* stream);
+
+/* BatchNorm(+ReLU) backward of a unit whose only consumer is the max-pool described by `d` that
+ * applied the unit's affine + ReLU while reading (coclr_maxpool3d_fwd with in_scale / in_shift): the
+ * gradient of the normalised activation is the pool's dy at the arg-max positions and is never
+ * written.  Replaces aten::max_pool3d_with_indices_backward + aten::native_batch_norm_backward +
+ * threshold_backward (backbone/s3dg.py:151,162 behind :60-64).  y: the unit's convolution output
+ * [N][C][Ti][Hi][Wi]; pool_dy / pool_idx: [N][C][To][Ho][Wo]; sums: workspace of
+ * coclr_bn_backward_workspace(N, C) doubles; returns 1 when the pooled plane does not fit the LDS tile
+ * (the caller then runs the two separate calls). */
+int coclr_bn_act_backward_pooled(const coclr_pool_desc* d, const float* pool_dy,
+                                 const int32_t* pool_idx, const float* y, const float* scale,
+                                 const float* shift, const float* mean, const float* invstd,
+                                 double* sums, float* dy, float* dgamma, float* dbeta,
+                                 int64_t pool_dy_nstride, int64_t y_nstride, int64_t dy_nstride,
+                                 int relu, int training, void* stream);
 /* aten::adaptive_avg_pool3d(x, (1,1,1)) and its backward; planes = N*C. */
 int coclr_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t S, void* stream);
 int coclr_global_avgpool_bwd(const float* dy, float* dx, int64_t planes, int64_t S, void* stream);

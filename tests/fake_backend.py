@@ -242,6 +242,18 @@ def maxpool_bwd(geom, dy, indices, dx, accumulate=False):
         dx.copy_(g)
 
 
+def bn_act_backward_pooled(geom, pool_dy, indices, y, scale, shift, mean, invstd, sums_ws, dy, dgamma,
+                           dbeta, relu, training):
+    dz = torch.empty_like(y)
+    maxpool_bwd(geom, pool_dy, indices, dz)
+    bn_act_backward(dz, y, None, scale, shift, mean, invstd, sums_ws, dy, None, dgamma, dbeta, relu,
+                    training)
+
+
+def pooled_backward_fits(geom):
+    return True
+
+
 def global_avgpool_fwd(x, y):
     y.copy_(x.mean((2, 3, 4), keepdim=True))
 

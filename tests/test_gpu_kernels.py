@@ -358,6 +358,68 @@ def test_maxpool_with_fused_batchnorm_relu_input(k, s, p, shape):
     close(y1, ref2, rtol=1e-6, what="fused affine+pool")
 
 
+@pytest.mark.parametrize("k,s,p,shape", [((1, 3, 3), (1, 2, 2), (0, 1, 1), (3, 8, 4, 14, 14)),
+                                         ((3, 3, 3), (2, 2, 2), (1, 1, 1), (2, 5, 6, 12, 10)),
+                                         ((1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 64, 2, 56, 56)),
+                                         ((2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 6, 4, 8, 8))])
+@pytest.mark.parametrize("relu,training", [(True, True), (False, True), (True, False)])
+def test_batchnorm_backward_through_fused_pool(k, s, p, shape, relu, training):
+    """Backward of BatchNorm(+ReLU) -> max-pool with the pool's gradient taken in scattered form
+    (never materialising d(activation)): equals autograd of the three ATen operators in float64
+    (backbone/s3dg.py:60-64 followed by :151), and is BIT-identical to the product's own separate
+    pool-backward + BatchNorm-backward calls on everything but re-associated channel sums."""
+    from coclr_amd import ops
+    torch.manual_seed(17)
+    N, C_ = shape[0], shape[1]
+    yraw = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+    gamma = torch.randn(C_, dtype=torch.float64, requires_grad=True)      # both signs
+    beta = (torch.randn(C_, dtype=torch.float64) * 0.3).requires_grad_(True)
+    rm, rv = torch.randn(C_, dtype=torch.float64) * 0.1, torch.rand(C_, dtype=torch.float64) + 0.5
+    z = F.batch_norm(yraw, None if training else rm, None if training else rv, gamma, beta, training,
+                     0.1, 1e-3)
+    if relu:
+        z = torch.relu(z)
+    ref = F.max_pool3d(z, k, s, p)
+    dyp = torch.randn_like(ref)
+    ref.backward(dyp)
+    if training:
+        mean = yraw.detach().mean((0, 2, 3, 4))
+        invstd = (yraw.detach().var((0, 2, 3, 4), unbiased=False) + 1e-3).rsqrt()
+    else:
+        mean, invstd = rm, (rv + 1e-3).rsqrt()
+    scale = gamma.detach() * invstd
+    shift = beta.detach() - mean * scale
+    f = lambda t: dev(t.float())
+    g = ops.PoolGeom(N, C_, shape[2:], k, s, p)
+    yd = f(yraw.detach())
+    pool_y = torch.empty(N, C_, *g.odim, device="cuda")
+    idx = torch.empty(N, C_, *g.odim, dtype=torch.int32, device="cuda")
+    ops.maxpool_fwd(g, yd, pool_y, idx, in_scale=f(scale), in_shift=f(shift), in_relu=relu)
+    assert ops.pooled_backward_fits(g)
+    sums = torch.empty(ops.bn_backward_workspace(N, C_), dtype=torch.float64, device="cuda")
+    dy = torch.full(shape, float("nan"), device="cuda")
+    dg, db = torch.empty(C_, device="cuda"), torch.empty(C_, device="cuda")
+    ops.bn_act_backward_pooled(g, f(dyp), idx, yd, f(scale), f(shift), f(mean), f(invstd), sums, dy,
+                               dg, db, relu, training)
+    close(dy, yraw.grad.float(), rtol=2e-5, what="dy through fused pool")
+    close(dg, gamma.grad.float(), rtol=2e-5, what="dgamma")
+    close(db, beta.grad.float(), rtol=2e-5, what="dbeta")
+    # the separate calls
+    dz = torch.empty(shape, device="cuda")
+    ops.maxpool_bwd(g, f(dyp), idx, dz)
+    dy2 = torch.empty(shape, device="cuda")
+    dg2, db2 = torch.empty(C_, device="cuda"), torch.empty(C_, device="cuda")
+    ops.bn_act_backward(dz, yd, None, f(scale), f(shift), f(mean), f(invstd), sums, dy2, None, dg2, db2,
+                        relu, training)
+    close(dy, dy2, rtol=1e-6, what="fused vs separate dy")
+    close(dg, dg2, rtol=1e-6, what="fused vs separate dgamma")
+    # run-to-run bit-identical (no atomics anywhere in the pair of kernels)
+    dy3 = torch.empty(shape, device="cuda")
+    ops.bn_act_backward_pooled(g, f(dyp), idx, yd, f(scale), f(shift), f(mean), f(invstd), sums, dy3,
+                               dg2, db2, relu, training)
+    assert torch.equal(dy, dy3) and torch.equal(dg, dg2) and torch.equal(db, db2)
+
+
 def test_global_avgpool():
     from coclr_amd import ops
     x = torch.randn(3, 10, 2, 4, 4)
