@@ -256,6 +256,18 @@ class S3D(_Emitter):
                 _Group(b4[1:] + b5[:1]), _Group(b5[1:])]
         return groups
 
+    def _late_split(self):
+        """(everything up to MaxPool_4a, Mixed_4b..Mixed_5c): the second part is the launch-bound one
+        that engine.GRAPH_LATE replays from a hipGraph."""
+        pair = self.__dict__.get("_coclr_late_split")
+        if pair is None:
+            b4 = list(self.block4)
+            front = _Group(list(self.block1) + list(self.block2) + list(self.block3) + b4[:1])
+            late = _Group(b4[1:] + list(self.block5))
+            late.__dict__["_coclr_graph_late"] = True
+            pair = self.__dict__["_coclr_late_split"] = (front, late)
+        return pair
+
     def forward(self, x, n_index=None):
         """One autograd node per stage, like the reference's forward (backbone/s3dg.py:211-217).  With
         gradients enabled this lets the gradients of the late stages -- 216 of the 231 backbone tensors
@@ -263,6 +275,11 @@ class S3D(_Emitter):
         backward: its bucket all-reduce then overlaps the weight-gradient stream instead of forming a
         tail after the whole backward."""
         if not (torch.is_grad_enabled() and _split_stages()):
+            if engine.GRAPH_LATE and torch.is_grad_enabled():
+                front, late = self._late_split()
+                x = engine.run_module(front, x, n_index=n_index) if n_index is not None \
+                    else engine.run_module(front, x)
+                return engine.run_module(late, x)
             return engine.run_module(self, x, n_index=n_index) if n_index is not None \
                 else engine.run_module(self, x)
         groups = self._stage_groups()

@@ -900,7 +900,12 @@ class EngineFn(torch.autograd.Function):
 # DistributedDataParallel's buckets (grad_out) are written there by the captured kernels as well.
 # Same kernels, same order, same operands as the eager pass: results are bit-identical
 # (tests/test_gpu_model.py::test_graphed_query_encoder_matches_eager).
-GRAPH_QUERY = os.environ.get("COCLR_GRAPH_QUERY", "0") == "1"
+# COCLR_GRAPH_QUERY=late captures only modules flagged `_coclr_graph_late` -- the 8x8x8 / 4x4x4 stages
+# of S3D (Mixed_4b..5c: 60 % of the step's launches, 10-40 us kernels that the host cannot feed fast
+# enough at the START of backward, when it has no lead) -- and leaves the large early stages eager.
+_GRAPH_MODE = os.environ.get("COCLR_GRAPH_QUERY", "0")
+GRAPH_QUERY = _GRAPH_MODE == "1"
+GRAPH_LATE = _GRAPH_MODE == "late"
 _GRAPH_WARMUP = 2           # eager passes with an unchanged signature before capturing
 _STATIC_PTRS = set()        # addresses of static graph outputs (a later stage takes them in place)
 _CAPTURE_STREAMS = {}
@@ -1094,7 +1099,7 @@ def run_module(module, x, **kwargs):
     if params is None:
         params = module.__dict__["_coclr_params"] = list(module.parameters())
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-        if GRAPH_QUERY:
+        if GRAPH_QUERY or (GRAPH_LATE and module.__dict__.get("_coclr_graph_late")):
             ent = _graph_entry(module, x, params, kwargs)
             if ent is not None:
                 return GraphedFn.apply(ent, x, *params)

@@ -40,7 +40,17 @@ def _L():
     return _HANDLE
 
 
+# Diagnostic: COCLR_HOST_DELAY_US=<n> burns n microseconds of host time per kernel launch.  If the step
+# time does not move, the host is not on the critical path (tools/host_bound_probe.sh).
+_HOST_DELAY = float(os.environ.get("COCLR_HOST_DELAY_US", "0")) * 1e-6
+
+
 def _stream():
+    if _HOST_DELAY:
+        import time
+        t = time.perf_counter() + _HOST_DELAY
+        while time.perf_counter() < t:
+            pass
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -212,7 +212,7 @@ def test_graph_replay_matches_eager():
         assert torch.equal(sd_g[k], sd_e[k]), k
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, "late"])
 def test_graphed_query_encoder_matches_eager(split, monkeypatch):
     """COCLR_GRAPH_QUERY=1: after two eager passes the query encoder's forward AND backward (the tape,
     with its weight-gradient side stream) are captured into hipGraphs and replayed.  Same kernels, same
@@ -225,13 +225,14 @@ def test_graphed_query_encoder_matches_eager(split, monkeypatch):
     import model.pretrain as product
     from coclr_amd import engine
     from coclr_amd.backbone import s3dg
-    monkeypatch.setattr(s3dg, "_SPLIT_MODE", "1" if split else "0")
+    late = split == "late"       # COCLR_GRAPH_QUERY=late: only Mixed_4b..5c replayed, the rest eager
+    monkeypatch.setattr(s3dg, "_SPLIT_MODE", "1" if split is True else "0")
     gold = load_golden("infonce_s3d_small")
     cfg = gold["cfg"]
     base = build_model(cfg, product)
     results = []
     for graphed in (False, True):
-        monkeypatch.setattr(engine, "GRAPH_QUERY", graphed)
+        monkeypatch.setattr(engine, "GRAPH_LATE" if late else "GRAPH_QUERY", graphed)
         model = copy.deepcopy(base).cuda().train()
         opt = torch.optim.Adam([{"params": p} for _, p in model.named_parameters()], lr=1e-3,
                                weight_decay=1e-5)
@@ -248,6 +249,9 @@ def test_graphed_query_encoder_matches_eager(split, monkeypatch):
         torch.cuda.synchronize()
         if graphed:
             mods = [model.encoder_q[0]] if not split else model.encoder_q[0]._stage_groups()
+            if late:
+                mods = [model.encoder_q[0]._late_split()[1]]
+                assert "_coclr_graph_entries" not in model.encoder_q[0]._late_split()[0].__dict__
             for m in mods:
                 ents = list(m.__dict__["_coclr_graph_entries"].values())
                 assert any(e.fwd is not None and e.bwd is not None for e in ents), \
