@@ -232,6 +232,10 @@ def main():
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if world > 1:
+            # the comparison legs (caller's optimiser, unmodified loop, isolated rooflines) are
+            # single-GPU measurements; a scaling run reports `value` and nothing that could fail beside it
+            args.no_extra_legs = True
 
     from coclr_amd import _lib
     _lib.load()                      # fail loudly if the HIP library is missing

@@ -555,6 +555,10 @@ class InfoNCE(nn.Module):
             if pre is not None:
                 pre()
             return self._encode(encoder, src, n_index=n_index)
+        if ent.get("disabled"):
+            if pre is not None:
+                pre()
+            return self._encode(encoder, src, n_index=n_index)
         if "graph" not in ent:
             static_x = torch.empty((n_index.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype,
                                    device=dev)
@@ -567,10 +571,22 @@ class InfoNCE(nn.Module):
             cur = torch.cuda.current_stream(dev)
             cap = cur if cur != torch.cuda.default_stream(dev) else torch.cuda.Stream(device=dev)
             # thread-local capture: RCCL's watchdog thread keeps polling events meanwhile
-            with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+            try:
+                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                    if pre is not None:
+                        pre()
+                    out = self._encode(encoder, static_x)
+            except RuntimeError as e:
+                # nothing of a failed capture has executed: this (encoder, mode) stays on the eager
+                # path (same kernels, ~4 ms more host work per step) instead of ending the job
+                import warnings
+                warnings.warn("coclr_amd: hipGraph capture of the key encoder failed (%s); running "
+                              "it eagerly" % e)
+                ent["disabled"] = True
+                torch.cuda.synchronize(dev)
                 if pre is not None:
                     pre()
-                out = self._encode(encoder, static_x)
+                return self._encode(encoder, src, n_index=n_index)
             ent.update(graph=g, x=static_x, out=out)
         else:
             ops.gather_rows(src, n_index, ent["x"])
