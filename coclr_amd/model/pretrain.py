@@ -607,6 +607,10 @@ class InfoNCE(nn.Module):
         rank learn rank 0's permutation on the HOST without a device->host sync."""
         g = InfoNCE.__dict__.get("_HOST_GROUP")
         if g is None:
+            if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+                # single-node rendezvous: gloo would otherwise look up the host NAME, which a
+                # container need not be able to resolve
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             g = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
             InfoNCE._HOST_GROUP = g
         return g
