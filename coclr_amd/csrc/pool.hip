@@ -10,6 +10,7 @@
 #include "common.h"
 #include "../../include/coclr_hip.h"
 #include <math.h>
+#include <cstdlib>
 
 namespace {
 
@@ -207,15 +208,70 @@ maxpool3d_tiled_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
 // are disjoint, so within a class the read-modify-writes cannot collide, and the classes run in a
 // fixed order with a barrier in between -- every input element receives its <= 27 addends in the
 // same order every time.  Then the tile is written (or accumulated) to HBM with coalesced stores.
-__global__ void __launch_bounds__(256)
-maxpool3d_tiled_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, float* dx,
-                           const PoolGeom g, long dy_nstride, long dx_nstride, int accumulate,
-                           int G, int planes, int tfold) {
-  extern __shared__ float tile[];   // [G][Si]
-  const int Si = g.Ti * g.Hi * g.Wi, So = g.To * g.Ho * g.Wo;
-  const int pl0 = blockIdx.x * G;
-  const int gcount = min(G, planes - pl0);
-  for (int i = threadIdx.x; i < gcount * Si; i += 256) tile[i] = 0.f;
+// With the class counts known at compile time (PT, PH, PW > 0) and at most KQ outputs per thread and
+// class, every (arg-max, dy) pair of the workgroup is loaded UP FRONT -- one global round trip instead
+// of one per class (27 for the 3x3x3 / 1 pools) -- and the classes are then applied from registers
+// with an LDS-only barrier in between.  Same addends in the same order as the generic form.
+template <int PT, int PH, int PW, int KQ>
+struct ClassLoads {
+  int i[PT * PH * PW][KQ];
+  float v[PT * PH * PW][KQ];
+};
+
+template <int PT, int PH, int PW, int KQ>
+__device__ __forceinline__ void class_load(ClassLoads<PT, PH, PW, KQ>& L, const float* __restrict__ dy,
+                                           const int* __restrict__ idx, const PoolGeom& g,
+                                           long dy_nstride, int pl0, int gcount, int tfold, int Si,
+                                           int So) {
+#pragma unroll
+  for (int ct = 0; ct < PT; ++ct)
+#pragma unroll
+    for (int ch = 0; ch < PH; ++ch)
+#pragma unroll
+      for (int cw = 0; cw < PW; ++cw) {
+        const int cls = (ct * PH + ch) * PW + cw;
+        const int nt = (g.To - ct + PT - 1) / PT, nh = (g.Ho - ch + PH - 1) / PH,
+                  nw = (g.Wo - cw + PW - 1) / PW;
+        const int csize = (nt > 0 && nh > 0 && nw > 0) ? nt * nh * nw : 0;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+          const int q = threadIdx.x + k * 256;
+          L.i[cls][k] = -1;
+          L.v[cls][k] = 0.f;
+          if (q < gcount * csize) {
+            const int gi = q / csize;
+            int m = q - gi * csize;
+            const int a = m / (nh * nw);
+            m -= a * nh * nw;
+            const int b = m / nw, cc = m - b * nw;
+            const int o = ((a * PT + ct) * g.Ho + (b * PH + ch)) * g.Wo + (cc * PW + cw);
+            const int pl = pl0 + gi;
+            const int n = pl / g.C, c = pl - n * g.C;
+            L.i[cls][k] = gi * Si + idx[(long)pl * So + o] - (pl % tfold) * Si;
+            L.v[cls][k] = dy[(long)n * dy_nstride + (long)c * So + o];
+          }
+        }
+      }
+}
+
+// the tile's zero fill (or anything else written to LDS before) must be followed by no barrier of
+// its own: the first class starts with one
+template <int PT, int PH, int PW, int KQ>
+__device__ __forceinline__ void class_apply(const ClassLoads<PT, PH, PW, KQ>& L, float* tile) {
+#pragma unroll
+  for (int cls = 0; cls < PT * PH * PW; ++cls) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the loads stay in flight
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+      if (L.i[cls][k] >= 0) tile[L.i[cls][k]] += L.v[cls][k];
+  }
+}
+
+// generic form: class counts from the geometry, one global round trip per class
+__device__ __forceinline__ void class_scatter_generic(float* tile, const float* __restrict__ dy,
+                                                      const int* __restrict__ idx, const PoolGeom& g,
+                                                      long dy_nstride, int pl0, int gcount, int tfold,
+                                                      int Si, int So) {
   const int Pt = (g.kt + g.st - 1) / g.st, Ph = (g.kh + g.sh - 1) / g.sh, Pw = (g.kw + g.sw - 1) / g.sw;
   for (int ct = 0; ct < Pt; ++ct)
     for (int ch = 0; ch < Ph; ++ch)
@@ -238,6 +294,26 @@ maxpool3d_tiled_bwd_kernel(const float* __restrict__ dy, const int* __restrict__
           tile[gi * Si + i] += dy[(long)n * dy_nstride + (long)c * So + o];
         }
       }
+}
+
+template <int PT, int PH, int PW, int KQ>
+__global__ void __launch_bounds__(256)
+maxpool3d_tiled_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, float* dx,
+                           const PoolGeom g, long dy_nstride, long dx_nstride, int accumulate,
+                           int G, int planes, int tfold) {
+  extern __shared__ float tile[];   // [G][Si]
+  const int Si = g.Ti * g.Hi * g.Wi, So = g.To * g.Ho * g.Wo;
+  const int pl0 = blockIdx.x * G;
+  const int gcount = min(G, planes - pl0);
+  if constexpr (PT > 0) {
+    ClassLoads<PT, PH, PW, KQ> L;
+    class_load<PT, PH, PW, KQ>(L, dy, idx, g, dy_nstride, pl0, gcount, tfold, Si, So);
+    for (int i = threadIdx.x; i < gcount * Si; i += 256) tile[i] = 0.f;
+    class_apply<PT, PH, PW, KQ>(L, tile);
+  } else {
+    for (int i = threadIdx.x; i < gcount * Si; i += 256) tile[i] = 0.f;
+    class_scatter_generic(tile, dy, idx, g, dy_nstride, pl0, gcount, tfold, Si, So);
+  }
   __syncthreads();
   for (int gi = 0; gi < gcount; ++gi) {
     const int pl = pl0 + gi;
@@ -386,12 +462,28 @@ bn_pool_bwd_reduce_kernel(const float* __restrict__ pdy, const int* __restrict__
   const int* ip = pidx + ((long)n * C + c) * So;
   const float* yp = y + (long)n * y_nstride + (long)c * Si;
   float ag = 0.f, agx = 0.f;
-  for (int o = threadIdx.x; o < So; o += 256) {
-    float g = dp[o];
-    const float v = yp[ip[o]];
-    if (relu) g = fmaf(v, sc, sf) > 0.f ? g : 0.f;
-    ag += g;
-    agx += g * ((v - mu) * is);
+  // four outputs per trip: the arg-max loads of all four, then the four dependent gathers of y -- two
+  // round trips per four outputs instead of per output (same per-thread summation order)
+  for (int o0 = threadIdx.x; o0 < So; o0 += 1024) {
+    int ii[4];
+    float gg[4], vv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int o = o0 + k * 256;
+      ii[k] = o < So ? ip[o] : 0;
+      gg[k] = o < So ? dp[o] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vv[k] = yp[ii[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (o0 + k * 256 >= So) break;
+      float g = gg[k];
+      const float v = vv[k];
+      if (relu) g = fmaf(v, sc, sf) > 0.f ? g : 0.f;
+      ag += g;
+      agx += g * ((v - mu) * is);
+    }
   }
   double sg = block256_sum_d((double)ag, red);
   double sgx = block256_sum_d((double)agx, red);
@@ -401,6 +493,7 @@ bn_pool_bwd_reduce_kernel(const float* __restrict__ pdy, const int* __restrict__
   }
 }
 
+template <int PT, int PH, int PW, int KQ>
 __global__ void __launch_bounds__(256)
 bn_pool_bwd_apply_kernel(const float* __restrict__ pdy, const int* __restrict__ pidx,
                          const float* __restrict__ y, const float* __restrict__ scale,
@@ -415,11 +508,22 @@ bn_pool_bwd_apply_kernel(const float* __restrict__ pdy, const int* __restrict__ 
   const int Si = g.Ti * g.Hi * g.Wi, So = g.To * g.Ho * g.Wo;
   const int pl0 = blockIdx.x * G;
   const int gcount = min(G, planes - pl0);
+  ClassLoads<(PT > 0 ? PT : 1), (PT > 0 ? PH : 1), (PT > 0 ? PW : 1), (PT > 0 ? KQ : 1)> L;
+  if constexpr (PT > 0)           // in flight while the coefficients are formed
+    class_load<PT, PH, PW, KQ>(L, pdy, pidx, g, pdy_nstride, pl0, gcount, tfold, Si, So);
   for (int i = threadIdx.x; i < gcount * Si; i += 256) tile[i] = 0.f;
-  // coefficients of the channels this group touches (g.C counts folded planes: channel = (pl % C) / tfold)
+  // coefficients of the channels this group touches (g.C counts folded planes: channel = (pl % C) /
+  // tfold); neighbouring planes of a folded volume share their channel's
+  int cprev = -1;
   for (int gi = 0; gi < gcount; ++gi) {
     const int pl = pl0 + gi;
     const int c = (pl % g.C) / tfold;
+    if (c == cprev && !(pl / g.C == 0 && (pl % g.C) % tfold == 0)) {      // uniform
+      if (threadIdx.x == 0)       // the thread that wrote them
+        for (int j = 0; j < 3; ++j) coef[gi][j] = coef[gi - 1][j];
+      continue;
+    }
+    cprev = c;
     __syncthreads();
     if (threadIdx.x < 64) {
       double a0 = 0.0, a1 = 0.0;
@@ -449,28 +553,8 @@ bn_pool_bwd_apply_kernel(const float* __restrict__ pdy, const int* __restrict__ 
       }
     }
   }
-  const int Pt = (g.kt + g.st - 1) / g.st, Ph = (g.kh + g.sh - 1) / g.sh, Pw = (g.kw + g.sw - 1) / g.sw;
-  for (int ct = 0; ct < Pt; ++ct)
-    for (int ch = 0; ch < Ph; ++ch)
-      for (int cw = 0; cw < Pw; ++cw) {
-        __syncthreads();
-        const int nt = (g.To - ct + Pt - 1) / Pt, nh = (g.Ho - ch + Ph - 1) / Ph,
-                  nw = (g.Wo - cw + Pw - 1) / Pw;
-        if (nt <= 0 || nh <= 0 || nw <= 0) continue;
-        const int csize = nt * nh * nw;
-        for (int q = threadIdx.x; q < gcount * csize; q += 256) {
-          const int gi = q / csize;
-          int m = q - gi * csize;
-          const int a = m / (nh * nw);
-          m -= a * nh * nw;
-          const int b = m / nw, cc = m - b * nw;
-          const int o = ((a * Pt + ct) * g.Ho + (b * Ph + ch)) * g.Wo + (cc * Pw + cw);
-          const int pl = pl0 + gi;
-          const int n = pl / g.C, c = pl - n * g.C;
-          const int i = pidx[(long)pl * So + o] - (pl % tfold) * Si;
-          tile[gi * Si + i] += pdy[(long)n * pdy_nstride + (long)c * So + o];
-        }
-      }
+  if constexpr (PT > 0) class_apply<PT, PH, PW, KQ>(L, tile);
+  else class_scatter_generic(tile, pdy, pidx, g, pdy_nstride, pl0, gcount, tfold, Si, So);
   __syncthreads();
   for (int gi = 0; gi < gcount; ++gi) {
     const int pl = pl0 + gi;
@@ -712,6 +796,31 @@ extern "C" int coclr_maxpool3d_fwd(const coclr_pool_desc* d, const float* x, flo
   return 0;
 }
 
+// colour-class counts of a pool and the outputs a thread holds per class for G volumes per workgroup
+struct ClassShape { int pt, ph, pw, kq; };
+inline ClassShape class_shape(const PoolGeom& g, int G) {
+  ClassShape c;
+  c.pt = (g.kt + g.st - 1) / g.st; c.ph = (g.kh + g.sh - 1) / g.sh; c.pw = (g.kw + g.sw - 1) / g.sw;
+  const long m = (long)((g.To + c.pt - 1) / c.pt) * ((g.Ho + c.ph - 1) / c.ph) * ((g.Wo + c.pw - 1) / c.pw);
+  c.kq = (int)((G * m + 255) / 256);
+  static const bool off = getenv("COCLR_POOL_PRELOAD") && atoi(getenv("COCLR_POOL_PRELOAD")) == 0;
+  if (off) c.kq = 1 << 20;            // A/B switch: the generic one-round-trip-per-class form
+  return c;
+}
+
+template <int PT, int PH, int PW, int KQ>
+int launch_tiled_bwd(const float* dy, const int32_t* indices, float* dx, const PoolGeom& g,
+                     long dy_nstride, long dx_nstride, int accumulate, int G, int planes, int tfold,
+                     int Si, hipStream_t st) {
+  auto kern = maxpool3d_tiled_bwd_kernel<PT, PH, PW, KQ>;
+  static std::atomic<uint64_t> done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), kTileFloats * 4, done));
+  hipLaunchKernelGGL(kern, dim3((planes + G - 1) / G), dim3(256), (size_t)G * Si * sizeof(float), st,
+                     dy, indices, dx, g, dy_nstride, dx_nstride, accumulate, G, planes, tfold);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, const int32_t* indices,
                                    float* dx, int64_t dy_nstride, int64_t dx_nstride,
                                    int accumulate, void* stream) {
@@ -746,14 +855,16 @@ extern "C" int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, co
       // 256 threads (1024 workgroups still fill the chip four deep)
       G = 4096 / Si > 0 ? 4096 / Si : 1;
       while (G > 1 && (planes + G - 1) / G < 1024) G >>= 1;
-      static std::atomic<uint64_t> done{0};
-      COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(maxpool3d_tiled_bwd_kernel),
-                                     kTileFloats * 4, done));
-      hipLaunchKernelGGL(maxpool3d_tiled_bwd_kernel, dim3((planes + G - 1) / G), dim3(256),
-                         (size_t)G * Si * sizeof(float), (hipStream_t)stream, dy, indices, dx, g,
-                         (long)dy_nstride, (long)dx_nstride, accumulate, G, planes, tfold);
-      COCLR_LAUNCH_CHECK();
-      return 0;
+      const ClassShape cs = class_shape(g, G);
+      hipStream_t st = (hipStream_t)stream;
+#define POOL_BWD(a, b, c, q)                                                                         \
+  if (cs.pt == a && cs.ph == b && cs.pw == c && cs.kq <= q)                                          \
+    return launch_tiled_bwd<a, b, c, q>(dy, indices, dx, g, (long)dy_nstride, (long)dx_nstride,      \
+                                        accumulate, G, planes, tfold, Si, st);
+      POOL_BWD(1, 2, 2, 1) POOL_BWD(3, 3, 3, 1) POOL_BWD(2, 2, 2, 1) POOL_BWD(1, 1, 1, 2)
+#undef POOL_BWD
+      return launch_tiled_bwd<0, 0, 0, 0>(dy, indices, dx, g, (long)dy_nstride, (long)dx_nstride,
+                                          accumulate, G, planes, tfold, Si, st);
     }
   }
   const PoolGeom& g = g0;
@@ -787,16 +898,24 @@ extern "C" int coclr_bn_act_backward_pooled(const coclr_pool_desc* d, const floa
                      y, scale, shift, mean, invstd, sums, g0.C, So0, Si0, (long)pool_dy_nstride,
                      (long)y_nstride, relu);
   COCLR_LAUNCH_CHECK();
-  static std::atomic<uint64_t> done{0};
-  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(bn_pool_bwd_apply_kernel),
-                                 kTileFloats * 4, done));
   const double count = (double)g0.N * Si0;
-  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3((planes + G - 1) / G), dim3(256),
-                     (size_t)G * Si * sizeof(float), st, pool_dy, pool_idx, y, scale, shift, mean, invstd,
-                     sums, g0.N, count, training, dgamma, dbeta, dy, g, (long)pool_dy_nstride,
-                     (long)y_nstride, (long)dy_nstride, relu, G, planes, tfold);
-  COCLR_LAUNCH_CHECK();
-  return 0;
+  const ClassShape cs = class_shape(g, G);
+#define BN_POOL_BWD(a, b, c, q)                                                                      \
+  do {                                                                                               \
+    auto kern = bn_pool_bwd_apply_kernel<a, b, c, q>;                                                \
+    static std::atomic<uint64_t> done{0};                                                            \
+    COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), kTileFloats * 4, done));      \
+    hipLaunchKernelGGL(kern, dim3((planes + G - 1) / G), dim3(256), (size_t)G * Si * sizeof(float),  \
+                       st, pool_dy, pool_idx, y, scale, shift, mean, invstd, sums, g0.N, count,      \
+                       training, dgamma, dbeta, dy, g, (long)pool_dy_nstride, (long)y_nstride,       \
+                       (long)dy_nstride, relu, G, planes, tfold);                                    \
+    COCLR_LAUNCH_CHECK();                                                                            \
+    return 0;                                                                                        \
+  } while (0)
+  if (cs.pt == 1 && cs.ph == 2 && cs.pw == 2 && cs.kq <= 1) BN_POOL_BWD(1, 2, 2, 1);
+  if (cs.pt == 2 && cs.ph == 2 && cs.pw == 2 && cs.kq <= 1) BN_POOL_BWD(2, 2, 2, 1);
+  BN_POOL_BWD(0, 0, 0, 0);
+#undef BN_POOL_BWD
 }
 
 extern "C" int coclr_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t S,

@@ -100,3 +100,20 @@ for name, c, idim in [("Conv_1a.bn1", 64, (32, 64, 64)), ("Conv_1a.bn2", 64, (16
                                             None, dgb[0], dgb[1], True, True))
     mb = y.numel() * 4 / 1e6
     print("%-16s %9.1f | %8.3f %8.0f | %8.3f %8.0f" % (name, mb, ta, 2 * mb / ta, tb, 5 * mb / tb))
+
+# ---- fused pool + BatchNorm backward of the lazily pooled units ---------------------------------
+print()
+print("%-16s %9s | %8s" % ("pooled bn bwd", "|y| MB", "ms"))
+for name, c, idim, k, s, p in [("Conv_1a.bn2", 64, (16, 64, 64), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                               ("Conv_2c.bn2", 192, (16, 32, 32), (1, 3, 3), (1, 2, 2), (0, 1, 1))]:
+    if only and not any(o in name for o in only): continue
+    g = ops.PoolGeom(B, c, idim, k, s, p)
+    y = torch.randn(B, c, *idim, device=dev)
+    small = torch.rand(4, c, device=dev) + 0.5
+    py = torch.empty(B, c, *g.odim, device=dev); idx = torch.empty(B, c, *g.odim, dtype=torch.int32, device=dev)
+    ops.maxpool_fwd(g, y, py, idx, in_scale=small[2], in_shift=small[3], in_relu=True)
+    pdy = torch.randn_like(py); dy = torch.empty_like(y); dgb = torch.empty(2, c, device=dev)
+    sums = torch.empty(ops.bn_backward_workspace(B, c), dtype=torch.float64, device=dev)
+    t = timeit(lambda: ops.bn_act_backward_pooled(g, pdy, idx, y, small[2], small[3], small[0], small[1],
+                                                  sums, dy, dgb[0], dgb[1], True, True))
+    print("%-16s %9.1f | %8.3f" % (name, y.numel() * 4 / 1e6, t))
