@@ -485,11 +485,19 @@ def main():
                 roof_hbm["isolated"] = {"avg_launch_ms": round(bn_iso_ms, 4),
                                         "achieved": round(byts / (bn_iso_ms * 1e-3) / 1e9, 1),
                                         "frac": round(byts / (bn_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        # whole-step view against both rooflines (91.46 GF, 2145 MB per clip)
-        step_view = {"tflops_per_gpu": round(91.46e9 * B / (ms * 1e-3) / 1e12, 2),
-                     "frac_fp32_peak": round(91.46e9 * B / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                     "algorithmic_gbs_per_gpu": round(2145e6 * B / (ms * 1e-3) / 1e9, 1),
-                     "frac_hbm_peak": round(2145e6 * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # whole-step view against both rooflines: algorithmic GFLOP / MB per training sample at the
+        # reference clip size 3x32x128x128 (S3D InfoNCE 91.46 GF, 2145 MB; S3D CoCLR
+        # 114.9 GF with the sampler's forward; r50 231.6 GF, 3758 MB); other shapes: not priced
+        per = {("s3d", "infonce"): (91.46, 2145.0), ("s3d", "coclr"): (114.9, 2694.0),
+               ("r50", "infonce"): (231.6, 3758.0)}.get((args.net, args.model))
+        step_view = None
+        if per is not None and args.seq_len == 32 and args.img_dim == 128:
+            gf, mb = per
+            step_view = {"gflop_per_sample": gf, "mb_per_sample": mb,
+                         "tflops_per_gpu": round(gf * 1e9 * B / (ms * 1e-3) / 1e12, 2),
+                         "frac_fp32_peak": round(gf * 1e9 * B / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "algorithmic_gbs_per_gpu": round(mb * 1e6 * B / (ms * 1e-3) / 1e9, 1),
+                         "frac_hbm_peak": round(mb * 1e6 * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         rec = {
             "metric": "clips/sec (whole node) %s-%s seq_len=%d bs=%d/GPU" % (
                 {"s3d": "S3D", "s3dg": "S3D-G", "r50": "R2D3D50"}.get(args.net, args.net),
