@@ -338,6 +338,10 @@ def main():
     dt, t_host, calls_per_step, final_loss = timed_run(args.steps, True)
     timer.enabled = False
     assert dry or opt._plan is not None, "the single-launch Adam did not run"
+    # a number measured on a broken kernel is worse than no number
+    if not (final_loss == final_loss and abs(final_loss) < 1e6):
+        raise SystemExit("bench: the loss after the timed steps is %r -- refusing to report a throughput"
+                         % final_loss)
 
     # ---- the same step as an unpatched caller gets it: torch's own Adam over the 470 groups ----------
     caller = None
