@@ -304,15 +304,32 @@ bn_fwd_fused_kernel(const float* __restrict__ sum, const float* __restrict__ sum
   __syncthreads();
   const float sc = coef[0], sf = coef[1];
   if (VEC) {
+    // One workgroup walks its whole channel (these launches have fewer workgroups than the chip has CUs):
+    // four independent loads per thread and trip, or every trip costs a full memory round trip
     const int S4 = S >> 2, total = N * S4;
-    for (int e = threadIdx.x; e < total; e += 256) {
-      const int n = e / S4, i = e - n * S4;
-      float4 v = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
-      v.x = fmaf(v.x, sc, sf); v.y = fmaf(v.y, sc, sf); v.z = fmaf(v.z, sc, sf); v.w = fmaf(v.w, sc, sf);
-      if (relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    for (int e0 = threadIdx.x; e0 < total; e0 += 1024) {
+      float4 v[4];
+      long zo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + k * 256;
+        zo[k] = -1;
+        if (e < total) {
+          const int n = e / S4, i = e - n * S4;
+          v[k] = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
+          zo[k] = (long)n * z_nstride + (long)c * S + 4 * i;
+        }
       }
-      reinterpret_cast<float4*>(z + (long)n * z_nstride + (long)c * S)[i] = v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (zo[k] < 0) continue;
+        float4 w = v[k];
+        w.x = fmaf(w.x, sc, sf); w.y = fmaf(w.y, sc, sf); w.z = fmaf(w.z, sc, sf); w.w = fmaf(w.w, sc, sf);
+        if (relu) {
+          w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(z + zo[k]) = w;
+      }
     }
   } else {
     const int total = N * S;
@@ -341,19 +358,34 @@ bn_bwd_fused_kernel(const float* __restrict__ dz, const float* __restrict__ y,
   if (VEC) {
     const int S4 = S >> 2, total = N * S4;
     float ag = 0.f, agx = 0.f;
-    for (int e = threadIdx.x; e < total; e += 256) {
-      const int n = e / S4, i = e - n * S4;
-      const float4 d = reinterpret_cast<const float4*>(dz + (long)n * dz_nstride + (long)c * S)[i];
-      const float4 v = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
-      float g0 = d.x, g1 = d.y, g2 = d.z, g3 = d.w;
-      if (relu) {
-        g0 = fmaf(v.x, sc, sf) > 0.f ? g0 : 0.f; g1 = fmaf(v.y, sc, sf) > 0.f ? g1 : 0.f;
-        g2 = fmaf(v.z, sc, sf) > 0.f ? g2 : 0.f; g3 = fmaf(v.w, sc, sf) > 0.f ? g3 : 0.f;
+    // four independent (dz, y) loads per thread and trip (see bn_fwd_fused_kernel); the per-thread
+    // summation order is the one-element-per-trip loop's
+    for (int e0 = threadIdx.x; e0 < total; e0 += 1024) {
+      float4 dd[4], vv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + k * 256;
+        if (e < total) {
+          const int n = e / S4, i = e - n * S4;
+          dd[k] = reinterpret_cast<const float4*>(dz + (long)n * dz_nstride + (long)c * S)[i];
+          vv[k] = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
+        }
       }
-      ag += (g0 + g1) + (g2 + g3);
-      agx += g0 * ((v.x - mu) * is) + g1 * ((v.y - mu) * is) + g2 * ((v.z - mu) * is) +
-             g3 * ((v.w - mu) * is);
-      if ((e & 0xfff) == 0xfff) { sg += (double)ag; sgx += (double)agx; ag = agx = 0.f; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + k * 256;
+        if (e >= total) break;
+        const float4 d = dd[k], v = vv[k];
+        float g0 = d.x, g1 = d.y, g2 = d.z, g3 = d.w;
+        if (relu) {
+          g0 = fmaf(v.x, sc, sf) > 0.f ? g0 : 0.f; g1 = fmaf(v.y, sc, sf) > 0.f ? g1 : 0.f;
+          g2 = fmaf(v.z, sc, sf) > 0.f ? g2 : 0.f; g3 = fmaf(v.w, sc, sf) > 0.f ? g3 : 0.f;
+        }
+        ag += (g0 + g1) + (g2 + g3);
+        agx += g0 * ((v.x - mu) * is) + g1 * ((v.y - mu) * is) + g2 * ((v.z - mu) * is) +
+               g3 * ((v.w - mu) * is);
+        if ((e & 0xfff) == 0xfff) { sg += (double)ag; sgx += (double)agx; ag = agx = 0.f; }
+      }
     }
     sg += (double)ag; sgx += (double)agx;
   } else {
@@ -382,19 +414,34 @@ bn_bwd_fused_kernel(const float* __restrict__ dz, const float* __restrict__ y,
   }
   if (VEC) {
     const int S4 = S >> 2, total = N * S4;
-    for (int e = threadIdx.x; e < total; e += 256) {
-      const int n = e / S4, i = e - n * S4;
-      const float4 d = reinterpret_cast<const float4*>(dz + (long)n * dz_nstride + (long)c * S)[i];
-      const float4 v = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
-      float4 g = d;
-      if (relu) {
-        g.x = fmaf(v.x, sc, sf) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, sc, sf) > 0.f ? g.y : 0.f;
-        g.z = fmaf(v.z, sc, sf) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, sc, sf) > 0.f ? g.w : 0.f;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 1024) {
+      float4 dd[4], vv[4];
+      long yo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + k * 256;
+        yo[k] = -1;
+        if (e < total) {
+          const int n = e / S4, i = e - n * S4;
+          dd[k] = reinterpret_cast<const float4*>(dz + (long)n * dz_nstride + (long)c * S)[i];
+          vv[k] = reinterpret_cast<const float4*>(y + (long)n * y_nstride + (long)c * S)[i];
+          yo[k] = (long)n * dy_nstride + (long)c * S + 4 * i;
+        }
       }
-      float4 o;
-      o.x = fmaf(A, g.x, fmaf(B, v.x, D)); o.y = fmaf(A, g.y, fmaf(B, v.y, D));
-      o.z = fmaf(A, g.z, fmaf(B, v.z, D)); o.w = fmaf(A, g.w, fmaf(B, v.w, D));
-      reinterpret_cast<float4*>(dy + (long)n * dy_nstride + (long)c * S)[i] = o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (yo[k] < 0) continue;
+        const float4 v = vv[k];
+        float4 g = dd[k];
+        if (relu) {
+          g.x = fmaf(v.x, sc, sf) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, sc, sf) > 0.f ? g.y : 0.f;
+          g.z = fmaf(v.z, sc, sf) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, sc, sf) > 0.f ? g.w : 0.f;
+        }
+        float4 o;
+        o.x = fmaf(A, g.x, fmaf(B, v.x, D)); o.y = fmaf(A, g.y, fmaf(B, v.y, D));
+        o.z = fmaf(A, g.z, fmaf(B, v.z, D)); o.w = fmaf(A, g.w, fmaf(B, v.w, D));
+        *reinterpret_cast<float4*>(dy + yo[k]) = o;
+      }
     }
   } else {
     const int total = N * S;
