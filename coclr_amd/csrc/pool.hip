@@ -365,19 +365,39 @@ maxpool333_kernel(const float* __restrict__ x, float* __restrict__ y, int* __res
   const int tid = threadIdx.x;
   const int pl0 = blockIdx.x * PG;
   const int gcount = min(PG, planes - pl0);
-  for (int gi = 0; gi < gcount; ++gi) {
-    const int pl = pl0 + gi;
-    const int n = pl / g.C, c = pl - n * g.C;
-    const float* xp = x + (long)n * g.x_nstride + (long)c * S;
-    float* tp = xs + gi * S;
-    if ((g.x_nstride & 3) == 0) {
-      for (int i = tid; i < (S >> 2); i += 256) {
-        float4 v = reinterpret_cast<const float4*>(xp)[i];
-        v.x = pool_in(g, v.x, c); v.y = pool_in(g, v.y, c);
-        v.z = pool_in(g, v.z, c); v.w = pool_in(g, v.w, c);
-        reinterpret_cast<float4*>(tp)[i] = v;
+  if ((g.x_nstride & 3) == 0) {
+    // [PG][S] is one run of <= 1024 float4 slots: all of a thread's loads in flight at once
+    const int S4 = S >> 2, total4 = gcount * S4;
+    for (int e0 = tid; e0 < total4; e0 += 4 * 256) {
+      float4 r[4];
+      int chn[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + k * 256;
+        chn[k] = -1;
+        if (e < total4) {
+          const int gi = e / S4, i = e - gi * S4;
+          const int pl = pl0 + gi;
+          const int n = pl / g.C, c = pl - n * g.C;
+          r[k] = reinterpret_cast<const float4*>(x + (long)n * g.x_nstride + (long)c * S)[i];
+          chn[k] = c;
+        }
       }
-    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (chn[k] < 0) continue;
+        float4 v = r[k];
+        v.x = pool_in(g, v.x, chn[k]); v.y = pool_in(g, v.y, chn[k]);
+        v.z = pool_in(g, v.z, chn[k]); v.w = pool_in(g, v.w, chn[k]);
+        reinterpret_cast<float4*>(xs)[e0 + k * 256] = v;
+      }
+    }
+  } else {
+    for (int gi = 0; gi < gcount; ++gi) {
+      const int pl = pl0 + gi;
+      const int n = pl / g.C, c = pl - n * g.C;
+      const float* xp = x + (long)n * g.x_nstride + (long)c * S;
+      float* tp = xs + gi * S;
       for (int i = tid; i < S; i += 256) tp[i] = pool_in(g, xp[i], c);
     }
   }
