@@ -69,6 +69,7 @@ struct ConvArgs {
   float inv_plane1, inv_hw, inv_ww;
   int mtiles, ntiles, nchunks;
   int relu, accumulate;
+  int xcd;                // remap workgroup ids so that an XCD owns contiguous tiles
 };
 
 // sum over each 16-lane row (result in every lane of the row)
@@ -124,7 +125,15 @@ conv_igemm_kernel(const ConvArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- which tile --------------------------------------------------------
-  const int bid = blockIdx.x;
+  // XCD-aware: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its
+  // own L2.  Logical tile ids are remapped so that XCD x owns a CONTIGUOUS run of them: the cout tiles
+  // of one box of positions (which all read the same input window) then share an L2 instead of
+  // fetching the window once per XCD.
+  int bid = blockIdx.x;
+  if (a.xcd) {
+    const int per = (int)gridDim.x >> 3;
+    if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+  }
   const int mt = bid % a.mtiles;
   const int ntile = bid / a.mtiles;
   int r = ntile;
@@ -464,7 +473,11 @@ conv_wino_t_kernel(const ConvArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
+  if (a.xcd) {                        // XCD-aware tile ids (see conv_igemm_kernel)
+    const int per = (int)gridDim.x >> 3;
+    if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+  }
   const int mt = bid % a.mtiles;
   const int ntile = bid / a.mtiles;
   int r = ntile;
@@ -1940,6 +1953,10 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
   a.inv_ww = 1.0f / (float)p.WW;
   a.ntiles = p.ntiles; a.mtiles = 0; a.planeS = 0; a.nchunks = 0;
   a.relu = relu; a.accumulate = accumulate;
+  {
+    static const bool xcd_off = getenv("COCLR_XCD_MAP") && atoi(getenv("COCLR_XCD_MAP")) == 0;
+    a.xcd = !xcd_off;
+  }
   // every byte offset a workgroup forms must stay below the descriptors' 2 GiB range
   const double lim = 2147483648.0;
   const double xs = n_index ? (double)(d->Nx > 0 ? d->Nx : p.N) : (double)(1 << p.lTN);

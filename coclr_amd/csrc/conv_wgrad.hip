@@ -14,6 +14,8 @@
 // touches, then runs v_mfma_f32_32x32x2_f32 with k = position.  Partial tiles
 // go to [split][Cout][J]; a second kernel folds the splits (no atomics, so the
 // result is run-to-run deterministic).
+#include <cstdlib>
+
 #include "common.h"
 #include "conv_geom.h"
 
@@ -865,6 +867,14 @@ struct WPlan {
   size_t lds2;
 };
 
+// Split count as a multiple of 8: the grid is (split, ci tile, co tile) with the split fastest, and the
+// hardware deals consecutive workgroup ids round-robin over the 8 XCDs -- with S % 8 == 0 the workgroups
+// that stream the SAME boxes (same split, other tiles) sit on one XCD and share its L2.
+inline int xcd_round(int S) {
+  static const bool off = getenv("COCLR_XCD_MAP") && atoi(getenv("COCLR_XCD_MAP")) == 0;
+  return (!off && S >= 16) ? (S & ~7) : S;
+}
+
 // tile of the v2 kernel for a stencil: returns variant id or 0
 // stem: (1,7,7) over 3 channels -> conv_wgrad_stem_kernel; fills the v2 plan fields
 int pick_stem(const coclr_conv_desc* d, WPlan* w) {
@@ -935,7 +945,7 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
       int S = 512 / (w->mt2 * w->ct2);
       if (S > p.ntiles / 4) S = p.ntiles / 4;
       if (S < 1) S = 1;
-      w->S2 = S;
+      w->S2 = xcd_round(S);
       return 6;
     }
   }
@@ -964,7 +974,7 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
   int S = 512 / (w->mt2 * w->ct2);
   if (S > p.ntiles / 4) S = p.ntiles / 4;
   if (S < 1) S = 1;
-  w->S2 = S;
+  w->S2 = xcd_round(S);
   return id;
 }
 
