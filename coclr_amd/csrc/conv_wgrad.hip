@@ -1011,7 +1011,7 @@ int plan_wgrad(const coclr_conv_desc* d, WPlan* w) {
   int S = 768 / (w->jtiles * w->mtiles);
   if (S > p.ntiles / 4) S = p.ntiles / 4;
   if (S < 1) S = 1;
-  w->S = S;
+  w->S = xcd_round(S);
   return 0;
 }
 
