@@ -51,6 +51,22 @@ def lanes_for(run, dims):
     if "graph" in LANES_MODE:
         ok = ok and torch.cuda.is_current_stream_capturing()
     return ok
+# Test instrumentation (tests/_decisions.py): when set, called as DECISION_PROBE("relu", bn, mask) for
+# every differentiated BatchNorm+ReLU unit (mask = the unit's ReLU decisions, exactly the predicate the
+# kernels evaluate: fma(y, scale, shift) (+ residual) > 0) and DECISION_PROBE("pool", None, argmax) for
+# every differentiated max-pool, in emission order.  A gradient is a piecewise-smooth function of the
+# inputs; the pieces are these decisions.  Never set by the product.
+DECISION_PROBE = None
+
+
+def _probe_relu(bn, y, scale, shift, residual=None):
+    sh = (1, -1, 1, 1, 1)
+    z = torch.addcmul(shift.double().view(sh), y.double(), scale.double().view(sh)).float()
+    if residual is not None:
+        z = z + residual
+    DECISION_PROBE("relu", bn, z > 0)
+
+
 _SIDE = {}
 _SIDE_PRIORITY = int(os.environ.get("COCLR_WGRAD_PRIORITY", "0"))
 # weight-gradient closures per release window (Run.side_stream); 0 = hold everything until join_side
@@ -601,6 +617,9 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                          ep_scale=scale if last else None, ep_shift=shift if last else None,
                          relu=relu and last, n_index=n_index, accumulate=t > 0)
 
+    if run.save and DECISION_PROBE is not None and relu:
+        _probe_relu(bn, y, scale, shift, residual.view() if residual is not None else None)
+
     if run.save:
         x_needs = run.needs_grad(x)
         if n_index is not None and x_needs:
@@ -713,6 +732,8 @@ def pointwise_group(run, x, units):
             ops.bn_act_apply(y[:, c0:c0 + C_], scale, shift, None, out.view(), True)
         outs.append(out)
         saved.append((c0, C_, mean, invstd, scale, shift))
+        if run.save and DECISION_PROBE is not None:
+            _probe_relu(bn, y[:, c0:c0 + C_], scale, shift)
         c0 += C_
 
     if run.save:
@@ -776,6 +797,8 @@ def max_pool(run, x, kernel, stride, padding):
     else:
         ops.maxpool_fwd(g, x.view(), y, idx)
     out = Val(y)
+    if need and DECISION_PROBE is not None:
+        DECISION_PROBE("pool", None, idx)
     if need:
         xid = id(x.base)
 

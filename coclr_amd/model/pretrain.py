@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 import torch.distributed as dist
 
+from .. import engine as _engine
 from .. import ops
 from .. import optim as _optim
 from ..backbone.select_backbone import select_backbone
@@ -174,6 +175,8 @@ class _ReluFn(torch.autograd.Function):
         y = torch.empty_like(x)
         ops.relu_fwd(x, y)
         ctx.save_for_backward(y)
+        if _engine.DECISION_PROBE is not None and x.requires_grad:
+            _engine.DECISION_PROBE("relu", "head", y > 0)       # test instrumentation, see engine.py
         return y
 
     @staticmethod
