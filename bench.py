@@ -72,6 +72,9 @@ def parse():
                     help="launch-contract rehearsal on the host (gloo, tiny shapes): only valid when "
                          "the caller has replaced coclr_amd.ops by the tests' ATen double "
                          "(tests/bench_dryrun.py); never a measurement")
+    ap.add_argument("--hang-timeout", type=float, default=240.0,
+                    help="world > 1: seconds without progress (no new collective, no new step) after "
+                         "which a rank reports the exchange it is stuck in and the job ends")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="intra-op threads of the CPU baseline (16 is the fastest on the 128-core "
@@ -131,6 +134,97 @@ class KernelTimer:
         if not ev:
             return None, 0
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)
+
+
+class Watchdog:
+    """world > 1: a first contact with RCCL / xGMI must end in evidence, not in the driver's timeout.
+    A daemon thread watches (phase, number of collectives issued); when neither moves for `limit`
+    seconds the rank writes which exchange it last issued (coclr_amd.parallel.LAST names the call site
+    and the reference line it stands for) and ends the process; rank 0 also prints the contract's JSON
+    line with "value": null and the diagnosis, so the driver's record says what hung."""
+
+    def __init__(self, rank, world, limit, base_record):
+        import threading
+        from coclr_amd import parallel
+        self.rank, self.world, self.limit, self.base = rank, world, limit, base_record
+        self.parallel = parallel
+        self.phase = ["start", 0]
+        self.done = False
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def at(self, what):
+        self.phase[0], self.phase[1] = what, self.phase[1] + 1
+
+    def _run(self):
+        seen, since = None, time.monotonic()
+        while not self.done:
+            time.sleep(min(1.0, self.limit / 4))
+            cur = (self.phase[1], self.parallel.LAST[2])
+            if cur != seen:
+                seen, since = cur, time.monotonic()
+                continue
+            if time.monotonic() - since < self.limit:
+                continue
+            diag = {"error": "no progress for %.0f s" % self.limit, "rank": self.rank,
+                    "phase": self.phase[0], "last_collective": self.parallel.LAST[0],
+                    "collectives_issued": self.parallel.LAST[2]}
+            print("bench watchdog: " + json.dumps(diag), file=sys.stderr, flush=True)
+            if self.rank == 0:
+                rec = dict(self.base, value=None, ms_per_step=None, hang=diag)
+                print(json.dumps(rec), flush=True)
+            os._exit(5)
+
+
+def cross_rank_digest(model, device):
+    """What must be IDENTICAL on every rank after an optimiser step: the queue(s) and the pointer (every
+    rank enqueues the same gathered keys, model/pretrain.py:82-96), the query parameters (same averaged
+    gradients, same Adam) and the key parameters (same momentum update).  BatchNorm running statistics
+    are rank-local until the next forward's broadcast and are left out.  Returns (names, float64 vector:
+    plain and position-weighted sums, so that a permuted tensor does not pass)."""
+    names, vals = [], []
+    sd = model.state_dict()
+    for k in sorted(sd):
+        if k.startswith("queue"):
+            t = sd[k].detach().double().reshape(-1)
+            names.append(k)
+            vals += [t.sum(), (t * torch.arange(1, t.numel() + 1, dtype=torch.float64, device=t.device)).sum()]
+    for enc in ("encoder_q", "encoder_k"):
+        tot = torch.zeros((), dtype=torch.float64, device=device)
+        tot_abs = torch.zeros((), dtype=torch.float64, device=device)
+        for p in getattr(model, enc).parameters():
+            t = p.detach().double()
+            tot += t.sum()
+            tot_abs += t.abs().sum()
+        names.append(enc + ".parameters")
+        vals += [tot, tot_abs]
+    for k in ("encoder_q.0.Conv_1a.conv1.weight", "encoder_q.0.Mixed_5c.branch1.1.conv2.weight",
+              "encoder_q.0.conv1.weight", "encoder_q.4.weight", "encoder_k.4.weight"):
+        if k in sd:
+            t = sd[k].detach().double().reshape(-1)
+            names.append(k)
+            vals += [t.sum(), (t * torch.arange(1, t.numel() + 1, dtype=torch.float64, device=t.device)).sum()]
+    return names, torch.stack([v.to(device) for v in vals])
+
+
+def cross_rank_check(model, out, device, world):
+    """One checked step's evidence: replicas bit-identical, logits finite on every rank."""
+    names, digest = cross_rank_digest(model, device)
+    got = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(got, digest)
+    finite = torch.tensor([1.0 if bool(torch.isfinite(out).all()) else 0.0], device=device)
+    dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+    worst, where = 0.0, None
+    for r in range(1, world):
+        d = (got[r] - got[0]).abs()
+        if float(d.max()) > worst:
+            worst = float(d.max())
+            where = "%s on rank %d" % (names[int(d.argmax()) // 2], r)
+    return {"replicas_identical": worst == 0.0, "max_abs_digest_diff": worst, "first_mismatch": where,
+            "fields": names, "logits_finite_on_every_rank": bool(finite.item() == 1.0),
+            "what": "after one full step (fwd, loss, bwd, all-reduce, Adam, momentum, enqueue): float64 "
+                    "digests (sum and position-weighted sum) of the queue(s), the pointer and the "
+                    "query / key parameters, all-gathered and compared with rank 0's"}
 
 
 def cpu_baseline(args):
@@ -225,13 +319,18 @@ def main():
         if _ops.conv_fwd.__module__ == "coclr_amd.ops":
             raise SystemExit("--dry-run-host needs the tests' double (python tests/bench_dryrun.py)")
         device = torch.device("cpu")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=max(60.0, 2 * args.hang_timeout)))
         torch.cuda.synchronize = lambda *a, **k: None
         args.no_extra_legs = args.no_cpu_baseline = True
     else:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        import datetime
+        # RCCL's own watchdog fires after the bench's (which names the call site first)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device,
+                                timeout=datetime.timedelta(seconds=max(60.0, 2 * args.hang_timeout)))
         if world > 1:
             # the comparison legs (caller's optimiser, unmodified loop, isolated rooflines) are
             # single-GPU measurements; a scaling run reports `value` and nothing that could fail beside it
@@ -245,6 +344,12 @@ def main():
 
     K = args.moco_k or (2048 if world == 1 else 16384)
     B = args.batch
+    dog = None
+    if world > 1:
+        dog = Watchdog(rank, world, args.hang_timeout, {
+            "metric": "clips/sec (whole node)", "unit": "clips/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic"})
     torch.manual_seed(0)
     if args.model == "infonce":
         model = InfoNCE(args.net, 128, K, 0.999, 0.07)
@@ -310,6 +415,7 @@ def main():
                 acc["top1"], acc["top5"] = L.calc_mask_accuracy(out, mask, (1, 5))
             else:
                 loss = (- torch.log((torch.softmax(out, dim=1) * mask).sum(1))).mean()
+        acc["logits"] = out.detach()
         cur.zero_grad(set_to_none=True)
         loss.backward()
         cur.step()
@@ -332,8 +438,45 @@ def main():
         return float(tmax), t_host, (_lib.CALLS[0] - calls0) / nsteps, float(loss.detach())
 
     cur = opt
+    multi = None
+    if world > 1:
+        # ---- first contact: one CHECKED step, then two instrumented ones (per-collective wall time) ----
+        from coclr_amd import parallel as _par
+        import coclr_amd.model.pretrain as _impl
+        dog.at("checked step (first forward: buffer broadcast, gloo side group, shuffle exchange)")
+        step(0)
+        torch.cuda.synchronize()
+        check = cross_rank_check(model, acc["logits"], device, world)
+        dog.at("instrumented steps (collectives serialised and timed one by one)")
+        _par.TIMINGS = []
+        ninst = 2
+        for i in range(ninst):
+            step(i + 1)
+        torch.cuda.synchronize()
+        rows, _par.TIMINGS = _par.TIMINGS, None
+        agg = {}
+        for name, nbytes, ms in rows:
+            a = agg.setdefault(name, [0, 0.0, nbytes])
+            a[0] += 1
+            a[1] += ms
+        coll = [{"collective": name, "calls_per_step": round(a[0] / ninst, 2),
+                 "ms_per_call": round(a[1] / a[0], 3), "mbytes": round(a[2] / 1e6, 3),
+                 "gbs": round(a[2] / 1e6 / max(a[1] / a[0], 1e-6), 2)} for name, a in agg.items()]
+        multi = {"rccl_ranks": world if not dry else 0, "backend": dist.get_backend(),
+                 "shuffle_mode": _impl._SHUFFLE_MODE,
+                 "split_stages": True, "cross_rank": check, "collectives": coll,
+                 "collectives_ms_per_step_serialised": round(sum(a[1] for a in agg.values()) / ninst, 3),
+                 "collectives_note": "each call bracketed by device synchronisations in two extra, untimed "
+                                     "steps: its cost if nothing overlapped it, INCLUDING the wait for the "
+                                     "slowest rank to arrive; the timed steps run them asynchronously"}
+        if not check["replicas_identical"] or not check["logits_finite_on_every_rank"]:
+            print("bench: cross-rank check FAILED: %s" % json.dumps(check), file=sys.stderr, flush=True)
+    if dog is not None:
+        dog.at("warm-up steps")
     for i in range(args.warmup):
         step(i)
+    if dog is not None:
+        dog.at("timed steps")
     timer.enabled = not dry
     dt, t_host, calls_per_step, final_loss = timed_run(args.steps, True)
     timer.enabled = False
@@ -534,6 +677,8 @@ def main():
                          "host_floor = the same step at 4 clips/GPU, where only the host paces it",
             "abi_calls_per_step": round(calls_per_step, 1),
         }
+        if multi is not None:
+            rec["multi_gpu"] = multi
         if unmodified is not None:
             rec["value_unmodified_caller"] = unmodified
         if split is not None:
@@ -542,7 +687,11 @@ def main():
             rec["value_caller_optimizer"] = caller
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)
+    if dog is not None:
+        dog.at("final barrier")
     dist.barrier()
+    if dog is not None:
+        dog.done = True
     dist.destroy_process_group()
     if rank == 0:
         # last thing on stdout (RCCL prints its banner lazily during the run)

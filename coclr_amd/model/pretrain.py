@@ -24,6 +24,7 @@ import torch.distributed as dist
 
 from .. import engine as _engine
 from .. import ops
+from ..parallel import collective as _coll
 from .. import optim as _optim
 from ..backbone.select_backbone import select_backbone
 
@@ -76,7 +77,9 @@ def concat_all_gather(tensor):
     tensor = tensor.contiguous()
     out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
                       device=tensor.device)
-    dist.all_gather_into_tensor(out, tensor)
+    _coll("all_gather_into_tensor %s (pretrain.concat_all_gather; ref :14-25)" % (tuple(tensor.shape),),
+          lambda: dist.all_gather_into_tensor(out, tensor), out.numel() * out.element_size(),
+          tensor.device)
     return out
 
 
@@ -354,7 +357,10 @@ class InfoNCE(nn.Module):
             self._host_group()
             with torch.no_grad():
                 for flat in flats:
-                    dist.broadcast(flat, src=0)
+                    _coll("broadcast of the flat %s buffer allocation (pretrain._sync_buffers; DDP "
+                          "broadcast_buffers, main_nce.py:172)" % str(flat.dtype).replace("torch.", ""),
+                          lambda flat=flat: dist.broadcast(flat, src=0),
+                          flat.numel() * flat.element_size(), flat.device)
 
     # -- momentum encoder ---------------------------------------------------------
     def _build_momentum_table(self):
@@ -433,7 +439,8 @@ class InfoNCE(nn.Module):
         if world > 1 or device.type != "cuda":
             idx_shuffle = perm.to(device)
             if world > 1:
-                dist.broadcast(idx_shuffle, src=0)
+                _coll("broadcast of the permutation (pretrain._shuffle_indices; ref :115)",
+                      lambda: dist.broadcast(idx_shuffle, src=0), 8 * batch_size_all, device)
             idx_unshuffle = torch.argsort(idx_shuffle)
             return idx_shuffle.view(world, -1)[rank], idx_unshuffle
         st = self.__dict__.get("_perm_staging")
@@ -634,7 +641,8 @@ class InfoNCE(nn.Module):
         B = x2.shape[0]
         BW = B * world
         perm = torch.randperm(BW)                         # same RNG use as the reference (:112)
-        dist.broadcast(perm, src=0, group=self._host_group())
+        _coll("host broadcast of the permutation over gloo (pretrain._routed_shuffle; ref :115)",
+              lambda: dist.broadcast(perm, src=0, group=self._host_group()), 8 * BW)
         pn = perm.numpy()
         src = pn // B
         mine = np.nonzero(src == rank)[0]
@@ -665,8 +673,10 @@ class InfoNCE(nn.Module):
         sendbuf = torch.empty((B,) + tuple(x2.shape[1:]), dtype=x2.dtype, device=dev)
         ops.gather_rows(x2, order_t, sendbuf)
         recvbuf = torch.empty_like(sendbuf)
-        dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=out_splits,
-                               input_split_sizes=in_splits)
+        _coll("all_to_all_single of %d key clips (pretrain._routed_shuffle; ref :106,124)" % B,
+              lambda: dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=out_splits,
+                                             input_split_sizes=in_splits),
+              sendbuf.numel() * sendbuf.element_size(), dev)
         # the index vectors are views of a buffer the next step overwrites: the key path consumes
         # them (shuffle gather, un-shuffle) before this forward returns, on this stream
         return recvbuf, n_index, idx_unshuffle
@@ -683,19 +693,44 @@ class InfoNCE(nn.Module):
             return st
         from torch.multiprocessing.reductions import reduce_tensor
         local = [torch.empty(x2.shape, dtype=x2.dtype, device=x2.device) for _ in range(2)]
-        torch.cuda.current_stream(x2.device).synchronize()
+        if x2.is_cuda:
+            torch.cuda.current_stream(x2.device).synchronize()
         objs = [None] * world
-        dist.all_gather_object(objs, [reduce_tensor(t) for t in local], group=self._host_group())
-        peers = []
-        for r, lst in enumerate(objs):
-            if r == rank:
-                peers.append(local)
-            else:
-                mapped = [fn(*args) for fn, args in lst]
-                for t in mapped:
-                    if t.device != x2.device:
-                        t.reshape(-1)[:1].to(x2.device)      # makes torch enable peer access to it
-                peers.append(mapped)
+        err, peers, handles = None, [], None
+        try:
+            handles = [reduce_tensor(t) for t in local]
+        except Exception as e:              # hipIpcGetMemHandle refused: still take part in the gather
+            err = e
+        _coll("all_gather_object of the hipIpc handles over gloo (pretrain._peer_stage)",
+              lambda: dist.all_gather_object(objs, handles, group=self._host_group()))
+        try:
+            if err is None and any(o is None for o in objs):
+                raise RuntimeError("a peer could not export its staging buffers")
+            for r, lst in enumerate(objs if err is None else []):
+                if r == rank:
+                    peers.append(local)
+                else:
+                    mapped = [fn(*args) for fn, args in lst]
+                    for t in mapped:
+                        if t.device != x2.device:
+                            t.reshape(-1)[:1].to(x2.device)      # makes torch enable peer access to it
+                    peers.append(mapped)
+        except Exception as e:              # hipIpc across devices / processes refused on this system
+            err = e
+        # the outcome must be the same on every rank (a rank pulling while another routes would hang):
+        # agree on the host channel, and fall back TOGETHER
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+        _coll("host all_reduce(MIN) 'every rank mapped its peers' over gloo (pretrain._peer_stage)",
+              lambda: dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self._host_group()))
+        if int(ok) == 0:
+            global _SHUFFLE_MODE
+            import warnings
+            warnings.warn("coclr_amd: COCLR_SHUFFLE=pull is not available here (%s on rank %d); every "
+                          "rank falls back to the routed all-to-all"
+                          % (err if err is not None else "a peer could not map the staging buffers", rank))
+            _SHUFFLE_MODE = "routed"
+            self.__dict__["_peer_stage_state"] = None
+            return None
         B = x2.shape[0]
         st = {"key": key, "local": local, "peers": peers, "step": 0,
               "base": np.array([[t.data_ptr() for t in pr] for pr in peers], dtype=np.int64),
@@ -719,10 +754,13 @@ class InfoNCE(nn.Module):
         B = x2.shape[0]
         BW = B * world
         st = self._peer_stage(x2)
+        if st is None:
+            return None
         par = st["step"] & 1
         st["step"] += 1
         perm = torch.randperm(BW)                         # same RNG use as the reference (:112)
-        dist.broadcast(perm, src=0, group=self._host_group())
+        _coll("host broadcast of the permutation over gloo (pretrain._pull_shuffle; ref :115)",
+              lambda: dist.broadcast(perm, src=0, group=self._host_group()), 8 * BW)
         pn = perm.numpy()
         dev = x2.device
         if st["host"] is None:
@@ -739,7 +777,8 @@ class InfoNCE(nn.Module):
         ev.record()
         st["event"] = ev
         ops.gather_rows(x2, st["ident"], st["local"][par])       # park my clips (x2 is a strided view)
-        dist.all_reduce(st["sync"])                              # stream-ordered: everybody has parked
+        _coll("one-element all_reduce = 'everybody has parked' (pretrain._pull_shuffle)",
+              lambda: dist.all_reduce(st["sync"]), 4, dev)          # stream-ordered barrier
         recv = torch.empty_like(st["local"][par])
         ops.pull_rows(st["dev"][:B], recv, keep=st["peers"])
         return recv, st["ident"], st["dev"][B:]
@@ -750,8 +789,9 @@ class InfoNCE(nn.Module):
         Returns (k for this rank's samples, keys of the whole global batch in order)."""
         world, rank = _world()
         B = x2.shape[0]
-        if world > 1 and _SHUFFLE_MODE == "pull":
-            src, n_index, idx_unshuffle = self._pull_shuffle(x2)
+        pulled = self._pull_shuffle(x2) if world > 1 and _SHUFFLE_MODE == "pull" else None
+        if pulled is not None:
+            src, n_index, idx_unshuffle = pulled
         elif world > 1 and _ROUTED_SHUFFLE:
             src, n_index, idx_unshuffle = self._routed_shuffle(x2)
         elif world > 1:

@@ -41,6 +41,38 @@ def _positional_index():
 _POS = _positional_index()
 _installed = [False]
 
+# ---- collectives: one choke point ---------------------------------------------------------------------
+# Every cross-rank call of the hot path goes through `collective(name, fn)`:
+#   * LAST holds (name, monotonic time, sequence number) of the most recent call: a watchdog (bench.py)
+#     that sees no progress can say WHICH exchange a rank is stuck in instead of timing out silently;
+#   * an exception out of the backend (gloo / RCCL timeout, peer gone) is re-raised naming the call site;
+#   * with TIMINGS set to a list, each call is bracketed by device synchronisations and its wall time is
+#     recorded as (name, bytes, milliseconds): an instrumented, serialised step -- never the timed region.
+LAST = ["", 0.0, 0]
+TIMINGS = None
+
+
+def collective(name, fn, nbytes=0, device=None):
+    import time
+    LAST[0], LAST[1], LAST[2] = name, time.monotonic(), LAST[2] + 1
+    timing = TIMINGS
+    if timing is not None and device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    try:
+        out = fn()
+        if timing is not None:
+            if hasattr(out, "wait"):
+                out.wait()
+            if device is not None and device.type == "cuda":
+                torch.cuda.synchronize(device)
+            timing.append((name, int(nbytes), (time.perf_counter() - t0) * 1e3))
+    except Exception as e:
+        raise RuntimeError("coclr_amd: collective '%s' failed after %.1f s: %s"
+                           % (name, time.perf_counter() - t0, e)) from e
+    return out
+
+
 
 class _HookState:
     def __init__(self, group):
@@ -67,8 +99,10 @@ def bucket_hook(state, bucket):
         fut.set_result(buf)
         return fut
     buf.div_(world)
-    return dist.all_reduce(buf, group=group, async_op=True).get_future().then(
-        lambda f: f.value()[0])
+    work = collective("ddp bucket %d all_reduce (parallel.bucket_hook; main_nce.py:172)" % idx,
+                      lambda: dist.all_reduce(buf, group=group, async_op=True),
+                      buf.numel() * buf.element_size(), buf.device)
+    return work.get_future().then(lambda f: f.value()[0])
 
 
 def install(module_types):

@@ -479,3 +479,103 @@ def test_bench_launch_contract_dry_run(world):
     assert rec["config"]["global_batch"] == 2 * world and "DRY RUN" in rec["data"]
     assert ("moco-k=16384" in rec["config"]["workload"]) == (world > 1)
     assert abs(rec["value"] - 2 * world * 2 / (rec["ms_per_step"] * 2e-3)) <= 0.02 * rec["value"]
+    if world == 1:
+        assert "multi_gpu" not in rec
+        return
+    # first-contact evidence: one checked step with cross-rank digests, then the
+    # per-collective wall times of two instrumented steps
+    mg = rec["multi_gpu"]
+    assert mg["shuffle_mode"] == "routed" and mg["split_stages"] is True
+    assert mg["cross_rank"]["replicas_identical"] is True, mg["cross_rank"]
+    assert mg["cross_rank"]["logits_finite_on_every_rank"] is True
+    assert {"queue", "queue_ptr", "encoder_q.parameters", "encoder_k.parameters"} <= set(mg["cross_rank"]["fields"])
+    names = " | ".join(c["collective"] for c in mg["collectives"])
+    for what in ("all_to_all_single", "all_gather_into_tensor", "ddp bucket 0 all_reduce",
+                 "broadcast of the flat float32 buffer", "host broadcast of the permutation"):
+        assert what in names, (what, names)
+    assert all(c["calls_per_step"] == 1.0 and c["ms_per_call"] > 0 for c in mg["collectives"])
+
+
+def test_bench_watchdog_names_the_stuck_collective():
+    """A rank that stops making progress reports the exchange it issued last and ends the job with the
+    contract's JSON line (value null) instead of hanging until the driver's timeout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import time, bench\n"
+            "from coclr_amd import parallel\n"
+            "parallel.LAST[0], parallel.LAST[2] = 'all_to_all_single of 32 key clips (test)', 7\n"
+            "d = bench.Watchdog(0, 8, 0.4, {'metric': 'clips/sec (whole node)', 'n_gpus': 8})\n"
+            "d.at('timed steps')\n"
+            "time.sleep(60)\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 5, (out.returncode, out.stderr[-2000:])
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["value"] is None and rec["n_gpus"] == 8
+    assert rec["hang"]["last_collective"].startswith("all_to_all_single") and rec["hang"]["phase"] == "timed steps"
+    assert "bench watchdog" in out.stderr
+
+
+def _pull_fallback_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        class MP:
+            @staticmethod
+            def setattr(obj, name, val):
+                setattr(obj, name, val)
+        fake_backend.install(MP)
+        import warnings
+        import torch.multiprocessing.reductions as red
+        import coclr_amd.model.pretrain as impl
+        import model.pretrain as product
+        if rank == 1:
+            def refuse(t):
+                raise RuntimeError("hipIpcGetMemHandle: invalid argument (simulated)")
+            red.reduce_tensor = refuse
+        B, K, clip = 2, 64, (3, 8, 32, 32)
+
+        def run(mode):
+            impl._SHUFFLE_MODE = mode
+            torch.manual_seed(0)
+            model = product.InfoNCE('s3d', 128, K, 0.999, 0.07)
+            model.train()
+            g = torch.Generator().manual_seed(50)
+            block = torch.randn(B * world, 2, *clip, generator=g)[rank * B:(rank + 1) * B]
+            torch.manual_seed(900)
+            with torch.no_grad():
+                out, _ = model(block)
+            return out
+
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got = run("pull")
+        assert impl._SHUFFLE_MODE == "routed", "the fallback must switch every rank to the routed exchange"
+        assert any("falls back to the routed" in str(w.message) for w in caught)
+        ref = run("routed")
+        assert torch.equal(got, ref)
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+def test_pull_shuffle_falls_back_to_routed_on_every_rank():
+    """COCLR_SHUFFLE=pull where ONE rank cannot export its staging buffers (hipIpc refused): all ranks
+    agree over the host channel and fall back to the routed all-to-all together -- no rank is left
+    waiting in a collective the others never enter."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pull_fallback_worker, args=(r, 2, 29741, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
