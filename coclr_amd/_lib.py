@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -55,6 +55,7 @@ _SIGNATURES = {
     "coclr_maxpool3d_bwd": [_P(PoolDesc), vp, vp, vp, i64, i64, i32, vp],
     "coclr_bn_act_backward_pooled": [_P(PoolDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64,
                                      i32, i32, vp],
+    "coclr_bn_act_backward_pooled_fits": [_P(PoolDesc), _P(i32)],
     "coclr_global_avgpool_fwd": [vp, vp, i64, i64, vp],
     "coclr_global_avgpool_bwd": [vp, vp, i64, i64, vp],
     "coclr_gemm_workspace": [i32, i32, i32, i32, _P(i64)],

@@ -102,8 +102,7 @@ __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, float*
 // takes ONE piece per channel instead of two scattered 4-byte ones.  a.WW / a.plane1 are then the padded
 // row / sample extents in floats, a.plane the number of granules, a.inv_* reciprocals in granules.
 template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false, bool XG = false>
-__global__ void __launch_bounds__(256)
-conv_igemm_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bid, const int nblocks) {
   constexpr int TAPS = KT * KH * KW;
   constexpr int WM = 2, WN = 2;
   constexpr int MF = BM / (WM * 32), NF = BN / (WN * 32);
@@ -129,9 +128,8 @@ conv_igemm_kernel(const ConvArgs a) {
   // own L2.  Logical tile ids are remapped so that XCD x owns a CONTIGUOUS run of them: the cout tiles
   // of one box of positions (which all read the same input window) then share an L2 instead of
   // fetching the window once per XCD.
-  int bid = blockIdx.x;
   if (a.xcd) {
-    const int per = (int)gridDim.x >> 3;
+    const int per = nblocks >> 3;
     if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
   }
   const int mt = bid % a.mtiles;
@@ -436,6 +434,25 @@ conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false, bool XG = false>
+__global__ void __launch_bounds__(256)
+conv_igemm_kernel(const ConvArgs a) {
+  conv_igemm_body<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// TWO problems of the same kernel variant in one launch: workgroups [0, nb0) run problem a0, the rest
+// problem a1 (the two separable branches of an inception block, backbone/s3dg.py:100-118, share every
+// stencil shape: on the 8x8x8 / 4x4x4 maps each of them alone is a 10-40 us launch that leaves most of
+// the chip idle).  Each half keeps its own XCD-aware tile numbering.
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false, bool XG = false>
+__global__ void __launch_bounds__(256)
+conv_igemm_pair_kernel(const ConvArgs a0, const ConvArgs a1, const int nb0) {
+  if ((int)blockIdx.x < nb0)
+    conv_igemm_body<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>(a0, (int)blockIdx.x, nb0);
+  else
+    conv_igemm_body<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+}
+
 // ------------------------------------------------------------------------------------
 // Temporal (3,1,1) stride-1 convolutions through Winograd F(2,3) along T.
 //
@@ -452,9 +469,8 @@ conv_igemm_kernel(const ConvArgs a) {
 // the B operand of virtual tap i is a difference or sum of two window rows (one VALU op), that a
 // wave keeps four accumulators per 32x32 block, and that the epilogue emits two frames.
 // 1.5x fewer MFMAs for the (3,1,1) layers (27 % of the S3D conv FLOPs), forward and dgrad.
-template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC = 1>
-__global__ void __launch_bounds__(256, OCC)
-conv_wino_t_kernel(const ConvArgs a) {
+template <int CC, int BM, int BNP, int PCH, bool XV4>
+__device__ __forceinline__ void conv_wino_t_body(const ConvArgs& a, int bid, const int nblocks) {
   constexpr int TAPS = 4;
   constexpr int WM = 2, WN = 2;
   constexpr int MF = BM / (WM * 32), NF = BNP / (WN * 32);
@@ -473,9 +489,8 @@ conv_wino_t_kernel(const ConvArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
 
-  int bid = blockIdx.x;
-  if (a.xcd) {                        // XCD-aware tile ids (see conv_igemm_kernel)
-    const int per = (int)gridDim.x >> 3;
+  if (a.xcd) {                        // XCD-aware tile ids (see conv_igemm_body)
+    const int per = nblocks >> 3;
     if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
   }
   const int mt = bid % a.mtiles;
@@ -744,24 +759,42 @@ conv_wino_t_kernel(const ConvArgs a) {
 }
 
 template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC = 1>
-int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
-  if (p.plane > PCH * 64) return COCLR_EINVAL;
-  a.mtiles = cdiv(a.Cout, BM);
-  // 16-byte staging packs the channel rows back to back
-  a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;
-  a.nchunks = cdiv(a.Cin, CC);
-  const size_t stage = ((size_t)4 * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
-  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
-  const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
-  const size_t lds = lds_main > lds_red ? lds_main : lds_red;
-  if (lds > 160 * 1024) return COCLR_EINVAL;
+__global__ void __launch_bounds__(256, OCC)
+conv_wino_t_kernel(const ConvArgs a) {
+  conv_wino_t_body<CC, BM, BNP, PCH, XV4>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// two problems in one launch, see conv_igemm_pair_kernel
+template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC)
+conv_wino_t_pair_kernel(const ConvArgs a0, const ConvArgs a1, const int nb0) {
+  if ((int)blockIdx.x < nb0) conv_wino_t_body<CC, BM, BNP, PCH, XV4>(a0, (int)blockIdx.x, nb0);
+  else conv_wino_t_body<CC, BM, BNP, PCH, XV4>(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+}
+
+struct PairSlot;
+template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC>
+int wino_t_single(const ConvArgs& a, long blocks, size_t lds, hipStream_t stream) {
   auto kern = conv_wino_t_kernel<CC, BM, BNP, PCH, XV4, OCC>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
-  hipLaunchKernelGGL(kern, dim3((unsigned)((long)a.mtiles * a.ntiles)), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
+
+template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC>
+int wino_t_pair(const ConvArgs& a0, const ConvArgs& a1, long b0, long b1, size_t lds, hipStream_t stream) {
+  auto kern = conv_wino_t_pair_kernel<CC, BM, BNP, PCH, XV4, OCC>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b0 + b1)), dim3(256), lds, stream, a0, a1, (int)b0);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC = 1>
+int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot = nullptr);
 
 // ------------------------------------------------------------------------------------
 // Spatial (1,3,3) stride-1 pad-1 convolutions through Winograd F(2x2,3x3).
@@ -1673,8 +1706,41 @@ inline int granule_count(const ConvPlan& p) {
   return ((p.WT * p.WH * ((1 << p.lTW) + 8)) << p.lTN) / 4;
 }
 
+// A launch that coclr_conv3d_fwd_multi may fuse with its neighbour: the launcher fills the slot instead of
+// launching; two slots with the same `pair` function are the same kernel variant.
+struct PairSlot {
+  ConvArgs args;
+  long blocks;
+  size_t lds;
+  int (*single)(const ConvArgs&, long, size_t, hipStream_t);
+  int (*pair)(const ConvArgs&, const ConvArgs&, long, long, size_t, hipStream_t);
+  bool pending;
+  // tile choice of a (1,3,3) direct launch, so that the second problem of a pair can be planned with it
+  int bm, lbn;
+};
+
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4, bool XG>
+int variant_single(const ConvArgs& a, long blocks, size_t lds, hipStream_t stream) {
+  auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4, bool XG>
+int variant_pair(const ConvArgs& a0, const ConvArgs& a1, long b0, long b1, size_t lds, hipStream_t stream) {
+  auto kern = conv_igemm_pair_kernel<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b0 + b1)), dim3(256), lds, stream, a0, a1, (int)b0);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false, bool XG = false>
-int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
+int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot = nullptr) {
   constexpr int TAPS = KT * KH * KW;
   a.mtiles = cdiv(a.Cout, BM);
   if (XG) {
@@ -1697,13 +1763,38 @@ int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
-  auto kern = conv_igemm_kernel<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>;
-  static std::atomic<uint64_t> attr_done{0};
-  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   const long blocks = (long)a.mtiles * a.ntiles;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
-  COCLR_LAUNCH_CHECK();
-  return 0;
+  // pair kernels exist for the stencil the two separable branches of an inception block share
+  constexpr bool PAIRABLE = KT == 1 && KH == 3 && KW == 3;
+  if (slot && PAIRABLE) {
+    slot->args = a; slot->blocks = blocks; slot->lds = lds; slot->pending = true;
+    slot->single = &variant_single<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>;
+    if constexpr (PAIRABLE) slot->pair = &variant_pair<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>;
+    return 0;
+  }
+  return variant_single<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>(a, blocks, lds, stream);
+}
+
+template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC>
+int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot) {
+  if (p.plane > PCH * 64) return COCLR_EINVAL;
+  a.mtiles = cdiv(a.Cout, BM);
+  // 16-byte staging packs the channel rows back to back
+  a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;
+  a.nchunks = cdiv(a.Cin, CC);
+  const size_t stage = ((size_t)4 * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
+  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
+  const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
+  const size_t lds = lds_main > lds_red ? lds_main : lds_red;
+  if (lds > 160 * 1024) return COCLR_EINVAL;
+  const long blocks = (long)a.mtiles * a.ntiles;
+  if (slot) {
+    slot->args = a; slot->blocks = blocks; slot->lds = lds; slot->pending = true;
+    slot->single = &wino_t_single<CC, BM, BNP, PCH, XV4, OCC>;
+    slot->pair = &wino_t_pair<CC, BM, BNP, PCH, XV4, OCC>;
+    return 0;
+  }
+  return wino_t_single<CC, BM, BNP, PCH, XV4, OCC>(a, blocks, lds, stream);
 }
 
 // efficiency of covering Cout with tiles of BM rows
@@ -1837,7 +1928,8 @@ extern "C" int coclr_conv_pack_batch(const int64_t* table, const int32_t* blockm
 namespace {
 
 // Fill plan + pick variant.  Returns 0 and the variant id, or an error.
-int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
+int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant, const Choice* force = nullptr,
+                 Choice* chosen = nullptr) {
   if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return COCLR_EINVAL;
   conv_normalise(d, p);
   const int kt = d->kt, kh = d->kh, kw = d->kw;
@@ -1866,6 +1958,13 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
     *variant = 60;
   } else if (kt == 1 && kh == 3 && kw == 3) {
     c = choose_tile(*p, 1, 3, 3, true, true, 256, 512);
+    if (force) {
+      // second problem of a pair: the first one's tile, when this geometry can take it
+      ConvPlan q = *p;
+      conv_pick_box(&q, force->lbn, 1, 3, 3);
+      if (q.plane <= (force->lbn == 6 ? 512 : 256)) c = *force;
+    }
+    if (chosen) *chosen = c;
     conv_pick_box(p, c.lbn, 1, 3, 3);
     if (c.lbn == 6) *variant = p->plane <= 256 ? 12 : 13;
     else *variant = c.bm == 128 ? 10 : 11;
@@ -1914,15 +2013,20 @@ extern "C" int coclr_conv3d_ntiles(const coclr_conv_desc* d, int* ntiles) {
   return 0;
 }
 
-extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const float* w_packed,
-                                float* y, float* stats, const float* bias, const float* ep_scale,
-                                const float* ep_shift, const int64_t* n_index, int relu,
-                                int accumulate, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+
+// The launch behind coclr_conv3d_fwd.  With `slot`, variants that have a pair kernel fill it instead of
+// launching (see PairSlot); `force` plans a (1,3,3) direct problem with a given tile.
+int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_packed, float* y,
+                    float* stats, const float* bias, const float* ep_scale, const float* ep_shift,
+                    const int64_t* n_index, int relu, int accumulate, hipStream_t stream,
+                    PairSlot* slot, const Choice* force) {
   ConvPlan p;
   int variant;
-  int rc = plan_forward(d, &p, &variant);
+  Choice chosen{0, 0};
+  int rc = plan_forward(d, &p, &variant, force, &chosen);
   if (rc) return rc;
+  if (slot) { slot->bm = chosen.bm; slot->lbn = chosen.lbn; }
   ConvArgs a;
   a.x = x; a.w = w_packed; a.y = y; a.stats = stats; a.bias = bias;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.n_index = n_index;
@@ -1988,14 +2092,14 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
     case 2:  return xv4 ? launch_variant<1, 1, 1, 16, 64, 64, 1, true>(a, p, stream)
                         : launch_variant<1, 1, 1, 32, 64, 64, 1>(a, p, stream);
     case 3:  return launch_variant<1, 1, 1, 16, 64, 64, 4>(a, p, stream);
-    case 10: return xg ? launch_variant<1, 3, 3, 4, 128, 128, 3, false, true>(a, p, stream)
-                       : launch_variant<1, 3, 3, 4, 128, 128, 4>(a, p, stream);
-    case 11: return xg ? launch_variant<1, 3, 3, 8, 64, 128, 3, false, true>(a, p, stream)
-                       : launch_variant<1, 3, 3, 8, 64, 128, 4>(a, p, stream);
-    case 12: return xg ? launch_variant<1, 3, 3, 8, 64, 64, 3, false, true>(a, p, stream)
-                       : launch_variant<1, 3, 3, 8, 64, 64, 4>(a, p, stream);
-    case 13: return xg ? launch_variant<1, 3, 3, 8, 64, 64, 3, false, true>(a, p, stream)
-                       : launch_variant<1, 3, 3, 8, 64, 64, 8>(a, p, stream);
+    case 10: return xg ? launch_variant<1, 3, 3, 4, 128, 128, 3, false, true>(a, p, stream, slot)
+                       : launch_variant<1, 3, 3, 4, 128, 128, 4>(a, p, stream, slot);
+    case 11: return xg ? launch_variant<1, 3, 3, 8, 64, 128, 3, false, true>(a, p, stream, slot)
+                       : launch_variant<1, 3, 3, 8, 64, 128, 4>(a, p, stream, slot);
+    case 12: return xg ? launch_variant<1, 3, 3, 8, 64, 64, 3, false, true>(a, p, stream, slot)
+                       : launch_variant<1, 3, 3, 8, 64, 64, 4>(a, p, stream, slot);
+    case 13: return xg ? launch_variant<1, 3, 3, 8, 64, 64, 3, false, true>(a, p, stream, slot)
+                       : launch_variant<1, 3, 3, 8, 64, 64, 8>(a, p, stream, slot);
     case 20: return xv4 ? launch_variant<3, 1, 1, 4, 128, 128, 4, true>(a, p, stream)
                         : launch_variant<3, 1, 1, 4, 128, 128, 4>(a, p, stream);
     case 21: return xv4 ? launch_variant<3, 1, 1, 8, 64, 128, 4, true>(a, p, stream)
@@ -2016,7 +2120,7 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
       // 99 registers; 27 KB of LDS): four waves per SIMD instead of three.  Measured at B=32 against
       // the 16-channel / three-wave form: Conv_2c.conv2 1.02-1.06 -> 0.99 ms forward, 0.907 -> 0.874
       // data gradient; Mixed_3c.b1.conv2 0.212 -> 0.204 / 0.205 -> 0.200; the 8x8x8 layers unchanged.
-      if (xv4) return launch_wino_t<8, 64, 64, 4, true, 4>(a, p, stream);
+      if (xv4) return launch_wino_t<8, 64, 64, 4, true, 4>(a, p, stream, slot);
       return launch_wino_t<16, 64, 64, 4, false>(a, p, stream);
     }
     case 60: {
@@ -2063,4 +2167,79 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
                         : launch_variant<7, 1, 1, 8, 64, 128, 8>(a, p, stream);
   }
   return COCLR_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const float* w_packed,
+                                float* y, float* stats, const float* bias, const float* ep_scale,
+                                const float* ep_shift, const int64_t* n_index, int relu,
+                                int accumulate, void* stream) {
+  return conv3d_fwd_impl(d, x, w_packed, y, stats, bias, ep_scale, ep_shift, n_index, relu, accumulate,
+                         (hipStream_t)stream, nullptr, nullptr);
+}
+
+namespace {
+// COCLR_PAIR=0: every problem of a multi call as its own launch, planned on its own (A/B switch, read per call)
+inline bool pair_enabled() {
+  const char* env = getenv("COCLR_PAIR");
+  return !(env && env[0] == '0');
+}
+}  // namespace
+
+extern "C" int coclr_conv3d_multi_ntiles(const coclr_conv_desc* const* descs, int n, int* ntiles) {
+  if (!descs || !ntiles || n < 1) return COCLR_EINVAL;
+  const bool fuse = pair_enabled();
+  for (int i = 0; i < n; i += 2) {
+    ConvPlan p;
+    int v;
+    Choice c0{0, 0};
+    int rc = plan_forward(descs[i], &p, &v, nullptr, &c0);
+    if (rc) return rc;
+    ntiles[i] = p.ntiles;
+    if (i + 1 < n) {
+      rc = plan_forward(descs[i + 1], &p, &v, fuse && c0.bm ? &c0 : nullptr, nullptr);
+      if (rc) return rc;
+      ntiles[i + 1] = p.ntiles;
+    }
+  }
+  return 0;
+}
+
+extern "C" int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!calls || n < 1) return COCLR_EINVAL;
+  const bool fuse = pair_enabled();
+  for (int i = 0; i < n; i += 2) {
+    const coclr_conv_call& c0 = calls[i];
+    if (i + 1 >= n || !fuse) {
+      for (int j = i; j < n && j < i + 2; ++j) {
+        const coclr_conv_call& c = calls[j];
+        int rc = conv3d_fwd_impl(c.d, c.x, c.w_packed, c.y, c.stats, c.bias, c.ep_scale, c.ep_shift,
+                                 c.n_index, c.relu, c.accumulate, stream, nullptr, nullptr);
+        if (rc) return rc;
+      }
+      continue;
+    }
+    const coclr_conv_call& c1 = calls[i + 1];
+    PairSlot s0, s1;
+    s0.pending = s1.pending = false;
+    s0.pair = s1.pair = nullptr;
+    s0.bm = s1.bm = 0;
+    int rc = conv3d_fwd_impl(c0.d, c0.x, c0.w_packed, c0.y, c0.stats, c0.bias, c0.ep_scale, c0.ep_shift,
+                             c0.n_index, c0.relu, c0.accumulate, stream, &s0, nullptr);
+    if (rc) return rc;
+    const Choice force{s0.bm, s0.lbn};
+    rc = conv3d_fwd_impl(c1.d, c1.x, c1.w_packed, c1.y, c1.stats, c1.bias, c1.ep_scale, c1.ep_shift,
+                         c1.n_index, c1.relu, c1.accumulate, stream, &s1, s0.bm ? &force : nullptr);
+    if (rc) return rc;
+    if (s0.pending && s1.pending && s0.pair && s0.pair == s1.pair) {
+      rc = s0.pair(s0.args, s1.args, s0.blocks, s1.blocks, s0.lds > s1.lds ? s0.lds : s1.lds, stream);
+      if (rc) return rc;
+    } else {
+      if (s0.pending) { rc = s0.single(s0.args, s0.blocks, s0.lds, stream); if (rc) return rc; }
+      if (s1.pending) { rc = s1.single(s1.args, s1.blocks, s1.lds, stream); if (rc) return rc; }
+    }
+  }
+  return 0;
 }

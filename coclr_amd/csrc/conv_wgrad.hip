@@ -238,7 +238,31 @@ struct Wgrad2Args {
   float inv_plane1, inv_hw, inv_ww;
   int ntiles, S;
   int To_full;            // Winograd form: a.To counts frame PAIRS, this is the real frame count
+  int xcd;                // XCD-aware (split, tile) ids, see wgrad_tile
 };
+
+// (split, ci tile, co tile) of this workgroup.  Plain: the launch grid's.  XCD-aware (a.xcd): the hardware
+// deals workgroups in linear order (x fastest) round-robin over the 8 XCDs; the linear id is remapped so
+// that XCD x owns a contiguous run of logical ids, and logical ids run TILE-fastest: the ct * mt workgroups
+// that stream the same boxes (one split) are neighbours in time on one XCD and share its L2 -- with the
+// split fastest they were a whole dispatch wave apart and every tile fetched both operands from HBM
+// (rocprofv3 FETCH_SIZE on Conv_2c.conv2: 3.3x the two tensors).
+struct WgTile { int split, ct, mt; };
+__device__ __forceinline__ WgTile wgrad_tile(int xcd) {
+  WgTile t;
+  t.split = blockIdx.x; t.ct = blockIdx.y; t.mt = blockIdx.z;
+  if (xcd) {
+    const int tiles = (int)(gridDim.y * gridDim.z), total = (int)gridDim.x * tiles;
+    int lin = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    const int per = total >> 3;
+    if (lin < (per << 3)) lin = (lin & 7) * per + (lin >> 3);
+    t.split = lin / tiles;
+    const int tile = lin - t.split * tiles;
+    t.mt = tile / (int)gridDim.y;
+    t.ct = tile - t.mt * (int)gridDim.y;
+  }
+  return t;
+}
 
 __device__ __forceinline__ int w2_fdiv(int e, float inv) { return (int)(((float)e + 0.5f) * inv); }
 
@@ -267,8 +291,9 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x;
-  const int ci0 = blockIdx.y * BCt, co0 = blockIdx.z * BMt;
+  const WgTile wt = wgrad_tile(a.xcd);
+  const int split = wt.split;
+  const int ci0 = wt.ct * BCt, co0 = wt.mt * BMt;
   const int nbox = (a.ntiles - split + a.S - 1) / a.S;
   const int lW = a.lTW, lWH = a.lTW + a.lTH, lWHT = a.lTW + a.lTH + a.lTT;
 
@@ -508,8 +533,9 @@ conv_wgrad_pw_kernel(const Wgrad2Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x;
-  const int ci0 = blockIdx.y * BCt, co0 = blockIdx.z * BMt;
+  const WgTile wt = wgrad_tile(a.xcd);
+  const int split = wt.split;
+  const int ci0 = wt.ct * BCt, co0 = wt.mt * BMt;
   const int nbox = (a.ntiles - split + a.S - 1) / a.S;
   const int S = a.Wi;                                   // flattened plane size
   const int boxes_per_sample = S >> 6;
@@ -875,6 +901,15 @@ inline int xcd_round(int S) {
   return (!off && S >= 16) ? (S & ~7) : S;
 }
 
+// Order of the (split, ci tile, co tile) workgroups of the second-generation / pointwise kernels, see
+// wgrad_tile(): 1 = tile-fastest XCD-aware ids, 0 = the launch grid's split-fastest order.
+// COCLR_WGRAD_ORDER=split|tile forces one (read per call: tools/wgrad_order_ab.py alternates in-process).
+inline int wgrad_order_env() {
+  const char* e = getenv("COCLR_WGRAD_ORDER");
+  if (!e) return -1;
+  return e[0] == 't' ? 1 : (e[0] == 's' ? 0 : -1);
+}
+
 // tile of the v2 kernel for a stencil: returns variant id or 0
 // stem: (1,7,7) over 3 channels -> conv_wgrad_stem_kernel; fills the v2 plan fields
 int pick_stem(const coclr_conv_desc* d, WPlan* w) {
@@ -976,6 +1011,19 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
   if (S < 1) S = 1;
   w->S2 = xcd_round(S);
   return id;
+}
+
+// Policy (measured per launch on one MI355X, tools/wgrad_order_ab.py, profiles/r04_wgrad_order.txt; traffic
+// in profiles/r04_pmc_wgrad.txt): tile-fastest XCD-aware ids when ONE SAMPLE of the input no longer fits an
+// XCD's 4 MiB L2.  Above that size, which XCD streams which boxes decides whether the halo rows of a
+// (1,3,3) window and the other half of a 128-byte line of a 16-float temporal row are fetched once or once
+// per XCD (Conv_2c.conv2 0.898 -> 0.863 ms, Conv_1a.conv2 1.051 -> 0.992); below it every L2 ends up
+// holding the whole sample either way and the launch grid's own order dispatches a few percent better
+// (128->128 (3,1,1) on 8x8x8: 0.023 vs 0.027 ms).
+inline int wgrad_tile_fastest(const coclr_conv_desc* d) {
+  const int forced = wgrad_order_env();
+  if (forced >= 0) return forced;
+  return (double)d->Cin * d->Ti * d->Hi * d->Wi * 4.0 >= 4.0 * 1024 * 1024;
 }
 
 int plan_wgrad(const coclr_conv_desc* d, WPlan* w) {
@@ -1101,6 +1149,7 @@ extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x
     a.inv_ww = 1.0f / (float)p.WW;
     a.ntiles = p.ntiles; a.S = w.S2;
     a.To_full = d->To;
+    a.xcd = wgrad_tile_fastest(d);
     if (w.v2 == 6) a.dy_cstride = d->To * p.Ho * p.Wo;     // p.To counts pairs there
     const int pch = cdiv(p.plane, 64);
     const bool pw = w.pw && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0;

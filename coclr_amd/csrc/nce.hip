@@ -705,6 +705,10 @@ extern "C" int coclr_mine_positives(const float* kf, const float* queue_second, 
   if (!kf || !queue_second || !src || !names || !mask || !counters) return COCLR_EINVAL;
   if (B <= 0 || K <= 0 || D != 128 || topk < 0 || topk > 16 || topk > K) return COCLR_EINVAL;
   if (topk > 0 && (!cand_val || !cand_idx)) return COCLR_EINVAL;
+  // the row-tile counters must be zero on entry; a launch that was aborted, or a workspace another
+  // stream is still using, would otherwise leave them non-zero and every later merge would fire early or
+  // never: zero them in stream order (B/32 ints).  The workspace is single-stream.
+  COCLR_RETURN_IF(hipMemsetAsync(counters, 0, sizeof(int32_t) * (size_t)cdiv(B, 32), (hipStream_t)stream));
   hipLaunchKernelGGL(mine_positives_kernel<128>, dim3(cdiv(K, 64), cdiv(B, 32)), dim3(256), 0,
                      (hipStream_t)stream, kf, queue_second, src, names, mask, cand_val, cand_idx,
                      counters, sim_out, B, K, topk);

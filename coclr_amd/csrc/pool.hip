@@ -895,6 +895,13 @@ extern "C" int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, co
   return 0;
 }
 
+extern "C" int coclr_bn_act_backward_pooled_fits(const coclr_pool_desc* d, int* fits) {
+  if (!d || !fits || d->N <= 0 || d->C <= 0) return COCLR_EINVAL;
+  const PoolGeom g = fold_time(to_geom(d));
+  *fits = g.Ti * g.Hi * g.Wi <= kTileFloats;
+  return 0;
+}
+
 extern "C" int coclr_bn_act_backward_pooled(const coclr_pool_desc* d, const float* pool_dy,
                                             const int32_t* pool_idx, const float* y,
                                             const float* scale, const float* shift,
@@ -908,7 +915,7 @@ extern "C" int coclr_bn_act_backward_pooled(const coclr_pool_desc* d, const floa
   const int tfold = g.Ti == g0.Ti ? 1 : g0.Ti;
   const int Si = g.Ti * g.Hi * g.Wi;
   const int planes = g.N * g.C;
-  if (Si > kTileFloats) return COCLR_EINVAL;          // the caller falls back to the separate passes
+  if (Si > kTileFloats) return COCLR_EINVAL;          // see coclr_bn_act_backward_pooled_fits
   int G = 4096 / Si > 0 ? 4096 / Si : 1;
   if (G > 8) G = 8;
   while (G > 1 && (planes + G - 1) / G < 1024) G >>= 1;

@@ -148,6 +148,8 @@ class LinearClassifier(nn.Module):
         else:
             self.final_fc = nn.Sequential(FeatureLinear(fs, self.num_class))
         self._initialize_weights(self.final_fc)
+        from .. import optim as _optim
+        _optim.register_model(self)          # its parameters may take the single-launch Adam step
 
     def forward(self, block):
         (B, C, T, H, W) = block.shape

@@ -243,7 +243,7 @@ def pool_geom(N, Cc, idim, k, s, p):
 
 
 class PoolGeom:
-    __slots__ = ("N", "C", "idim", "odim", "k", "s", "p", "desc", "desc_bw")
+    __slots__ = ("N", "C", "idim", "odim", "k", "s", "p", "desc", "desc_bw", "_pooled_fits")
 
     def __init__(self, N, Cc, idim, k, s, p):
         self.N, self.C = int(N), int(Cc)
@@ -255,6 +255,7 @@ class PoolGeom:
             raise ValueError("coclr_amd: pooling output would be empty")
         self.desc = PoolDesc(self.N, self.C, *self.idim, *self.odim, *self.k, *self.s, *self.p, 0, 0)
         self.desc_bw = None
+        self._pooled_fits = None
 
 
 # ---- convolution ---------------------------------------------------------------
@@ -437,11 +438,19 @@ def bn_act_backward_pooled(geom, pool_dy, indices, y, scale, shift, mean, invstd
 
 
 def pooled_backward_fits(geom):
-    """The fused form stages one (folded) input plane of the pool in LDS (csrc/pool.hip kTileFloats)."""
-    t, h, w = geom.idim
-    if geom.k[0] == 1 and geom.s[0] == 1 and geom.p[0] == 0:
-        t = 1
-    return t * h * w <= 16384
+    """Does bn_act_backward_pooled take this pool?  Asked of the library (the answer depends on the
+    kernel's LDS tiling), once per geometry."""
+    v = getattr(geom, "_pooled_fits", None)
+    if v is None:
+        out = C.c_int32(0)
+        _lib.check(_L().coclr_bn_act_backward_pooled_fits(C.byref(geom.desc), C.byref(out)),
+                   "bn_act_backward_pooled_fits")
+        v = bool(out.value)
+        try:
+            geom._pooled_fits = v
+        except AttributeError:
+            pass
+    return v
 
 
 def global_avgpool_fwd(x, y):

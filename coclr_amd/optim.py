@@ -26,10 +26,30 @@ _TorchAdam = torch.optim.Adam
 _MOMENTUM_MODELS = weakref.WeakSet()
 
 
+_OWN_MODELS = weakref.WeakSet()
+
+
 def register_momentum_model(model):
     """InfoNCE / UberNCE / CoCLR instances announce themselves so that `Adam(fold_momentum=True)`
     can find the (query, key) parameter pairs of model/pretrain.py:76-80."""
     _MOMENTUM_MODELS.add(model)
+    _OWN_MODELS.add(model)
+
+
+def register_model(model):
+    """Any module of this package whose parameters the single-launch step may take (the linear-probe
+    classifier).  `torch.optim.Adam` resolves to the subclass process-wide once `model.pretrain` is
+    imported; optimisers over parameters that belong to NO registered module behave exactly as torch's."""
+    _OWN_MODELS.add(model)
+
+
+def _owns_any(params):
+    ids = {id(p) for p in params}
+    for model in list(_OWN_MODELS):
+        for p in model.parameters():
+            if id(p) in ids:
+                return True
+    return False
 
 
 class Adam(_TorchAdam):
@@ -42,6 +62,8 @@ class Adam(_TorchAdam):
     next training forward the key encoder is one momentum step AHEAD of where the reference has
     it -- a checkpoint written in that window, or a no-grad forward, sees the updated keys."""
 
+    _scoped = False     # ScopedAdam: the native step only for parameters of this package's modules
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0,
                  amsgrad=False, *, fold_momentum=None, **kw):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
@@ -50,11 +72,17 @@ class Adam(_TorchAdam):
             fold_momentum = os.environ.get("COCLR_FOLD_MOMENTUM", "0") == "1"
         self._fold = bool(fold_momentum)
         self._plan = None
+        self._ours = None       # decided at the first step: do these parameters belong to this package?
 
     # -- eligibility ---------------------------------------------------------------------
     def _native_groups(self):
         """[(group, [params with grad])] if every parameter that has a gradient can take the
         kernel, else None (torch's implementation runs instead)."""
+        if self._ours is None:
+            self._ours = not self._scoped or os.environ.get("COCLR_ADAM_EVERYWHERE", "0") == "1" or \
+                _owns_any(p for g in self.param_groups for p in g["params"])
+        if not self._ours:
+            return None       # somebody else's model: torch's own implementation, untouched
         out = []
         dev = None
         for g in self.param_groups:
@@ -230,15 +258,26 @@ class Adam(_TorchAdam):
         return loss
 
 
+class ScopedAdam(Adam):
+    """What `torch.optim.Adam` resolves to after `install()`: `Adam`, except that an optimiser over
+    parameters that belong to NO module of this package (InfoNCE / UberNCE / CoCLR / LinearClassifier
+    register themselves) is torch's own implementation, step for step -- importing `model.pretrain`
+    must not change how somebody else's model in the same process is optimised.
+    `COCLR_ADAM_EVERYWHERE=1` lifts the restriction."""
+    _scoped = True
+
+
 def install():
     """Make `torch.optim.Adam` (what main_nce.py:200 / main_coclr.py:213 construct) resolve to the
-    single-launch subclass.  Idempotent; COCLR_PATCH_ADAM=0 leaves torch untouched."""
+    single-launch subclass, scoped to this package's models (ScopedAdam).  Idempotent;
+    COCLR_PATCH_ADAM=0 leaves torch untouched."""
     if os.environ.get("COCLR_PATCH_ADAM", "1") == "0":
         return False
-    if torch.optim.Adam is not Adam:
-        torch.optim.Adam = Adam
+    if torch.optim.Adam is not ScopedAdam:
+        torch.optim.Adam = ScopedAdam
         if os.environ.get("COCLR_QUIET", "0") != "1":
             import sys
-            print("coclr_amd: torch.optim.Adam resolves to the single-launch subclass "
-                  "(COCLR_PATCH_ADAM=0 opts out)", file=sys.stderr)
+            print("coclr_amd: torch.optim.Adam resolves to the single-launch subclass for parameters of "
+                  "InfoNCE / UberNCE / CoCLR / LinearClassifier modules (COCLR_PATCH_ADAM=0 opts out)",
+                  file=sys.stderr)
     return True

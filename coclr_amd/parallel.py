@@ -13,7 +13,9 @@ makes True the default when the caller did not say otherwise.  `COCLR_PATCH_DDP=
 With the gradients living in the buckets, the remaining per-parameter work is DDP's copy INTO the
 bucket (`mul_out(bucket_view, grad, 1/world)`: 235 launches of ~3 us on the critical stream, even at
 world size 1).  The shim therefore also registers a communication hook on wrappers it defaulted
-(`COCLR_DDP_HOOK=0` opts out; nothing is registered when the caller chose the flag): the hook
+(`COCLR_DDP_HOOK=0` opts out; nothing is registered when the caller chose the flag) -- at the wrapper's
+FIRST forward, and only if the caller has not registered a hook of their own by then (DDP accepts exactly
+one); the slots it publishes to the engine are dropped when the wrapper is garbage-collected: the hook
   * tells the engine where each parameter's gradient lives in the bucket (`engine.set_grad_slot`), so
     the next backward writes weight gradients straight into the bucket views and DDP, finding them
     there, copies nothing;
@@ -78,6 +80,37 @@ class _HookState:
     def __init__(self, group):
         self.group = group
         self.seen = {}        # bucket index -> (buffer address, #parameters) already published
+        self.published = {}   # id(param) -> weakref(param): slots this wrapper handed to the engine
+
+
+def _drop_slots(published):
+    """The wrapper is gone (re-wrap, or training continues on the bare model): its bucket storage must not
+    stay alive -- or keep being handed out as `.grad` memory -- through the engine's slot table."""
+    from . import engine
+    for ref in published.values():
+        p = ref()
+        if p is not None:
+            engine.set_grad_slot(p, None)
+    published.clear()
+
+
+def _register_lazily(ddp, _inputs):
+    """Forward pre-hook of a wrapper this shim defaulted: at its FIRST forward, register the bucket hook
+    unless the caller has registered a communication hook of their own meanwhile (DDP takes exactly
+    one: fp16 compression, PowerSGD, ... win, and the engine then simply gets no bucket views)."""
+    import weakref
+    st = ddp.__dict__.pop("_coclr_hook_pending", None)
+    if st is None:
+        return
+    state, handle = st
+    handle.remove()
+    if getattr(ddp, "_comm_hooks", None):
+        return
+    try:
+        ddp.register_comm_hook(state, bucket_hook)
+    except RuntimeError:
+        return                              # a hook is already there
+    weakref.finalize(ddp, _drop_slots, state.published)
 
 
 def bucket_hook(state, bucket):
@@ -89,8 +122,10 @@ def bucket_hook(state, bucket):
     sig = (buf.data_ptr(), buf.numel())
     idx = bucket.index()
     if state.seen.get(idx) != sig:
+        import weakref
         for p, g in zip(bucket.parameters(), bucket.gradients()):
             engine.set_grad_slot(p, g)
+            state.published[id(p)] = weakref.ref(p)
         state.seen[idx] = sig
     group = state.group if state.group is not None else dist.group.WORLD
     world = dist.get_world_size(group)
@@ -118,7 +153,8 @@ def install(module_types):
             kwargs["gradient_as_bucket_view"] = True
         orig(self, module, *args, **kwargs)
         if ours and os.environ.get("COCLR_DDP_HOOK", "1") != "0":
-            self.register_comm_hook(_HookState(self.process_group), bucket_hook)
+            handle = self.register_forward_pre_hook(_register_lazily)
+            self.__dict__["_coclr_hook_pending"] = (_HookState(self.process_group), handle)
 
     __init__.__wrapped__ = orig
     __init__.__doc__ = orig.__doc__
@@ -126,5 +162,7 @@ def install(module_types):
     _installed[0] = True
     if os.environ.get("COCLR_QUIET", "0") != "1":
         print("coclr_amd: DistributedDataParallel defaults to gradient_as_bucket_view=True for "
-              "InfoNCE/UberNCE/CoCLR modules (COCLR_PATCH_DDP=0 opts out)", file=sys.stderr)
+              "InfoNCE/UberNCE/CoCLR modules and, unless the caller registers a communication hook of their "
+              "own before the first forward, averages per bucket through one (COCLR_PATCH_DDP=0 / "
+              "COCLR_DDP_HOOK=0 opt out)", file=sys.stderr)
     return True

@@ -110,6 +110,30 @@ int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const float* w_pa
                      const float* ep_shift, const int64_t* n_index, int relu, int accumulate,
                      void* stream);
 
+/* Several INDEPENDENT convolutions in one call; consecutive pairs (0,1), (2,3), ... that resolve to the
+ * same kernel variant run as ONE launch whose grid holds the tiles of both problems.  Replaces two
+ * aten::conv3d calls of sibling branches: the (1,3,3) / (3,1,1) convolutions of branch1 and branch2 of an
+ * inception block (backbone/s3dg.py:100-118), forward and data gradient -- on the 8x8x8 / 4x4x4 maps each
+ * of them alone is a 10-40 us launch that leaves most of the chip idle.  Per-problem arguments are those
+ * of coclr_conv3d_fwd.  The second problem of a pair is planned with the first one's tile where it can
+ * take it, so its statistics layout is [2][Cout][ntiles] with the ntiles coclr_conv3d_multi_ntiles reports
+ * for the same list of geometries (NOT necessarily coclr_conv3d_ntiles of the problem alone).
+ * COCLR_PAIR=0 in the environment runs (and plans) every problem on its own. */
+typedef struct coclr_conv_call {
+  const coclr_conv_desc* d;
+  const float* x;
+  const float* w_packed;
+  float* y;
+  float* stats;
+  const float* bias;
+  const float* ep_scale;
+  const float* ep_shift;
+  const int64_t* n_index;
+  int32_t relu, accumulate;
+} coclr_conv_call;
+int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void* stream);
+int coclr_conv3d_multi_ntiles(const coclr_conv_desc* const* descs, int n, int* ntiles);
+
 /* Split-K workspace (fp32 elements) for coclr_conv3d_wgrad. */
 int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* elems);
 
@@ -210,14 +234,17 @@ int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, const int32_t
  * written.  Replaces aten::max_pool3d_with_indices_backward + aten::native_batch_norm_backward +
  * threshold_backward (backbone/s3dg.py:151,162 behind :60-64).  y: the unit's convolution output
  * [N][C][Ti][Hi][Wi]; pool_dy / pool_idx: [N][C][To][Ho][Wo]; sums: workspace of
- * coclr_bn_backward_workspace(N, C) doubles; returns 1 when the pooled plane does not fit the LDS tile
- * (the caller then runs the two separate calls). */
+ * coclr_bn_backward_workspace(N, C) doubles.  Only for pools whose (time-folded) input plane fits the
+ * kernel's LDS tile: coclr_bn_act_backward_pooled_fits answers that from the same tiling constants;
+ * a pool that does not fit is rejected with COCLR_EINVAL (1) and the caller runs
+ * coclr_maxpool3d_bwd + coclr_bn_act_backward instead. */
 int coclr_bn_act_backward_pooled(const coclr_pool_desc* d, const float* pool_dy,
                                  const int32_t* pool_idx, const float* y, const float* scale,
                                  const float* shift, const float* mean, const float* invstd,
                                  double* sums, float* dy, float* dgamma, float* dbeta,
                                  int64_t pool_dy_nstride, int64_t y_nstride, int64_t dy_nstride,
                                  int relu, int training, void* stream);
+int coclr_bn_act_backward_pooled_fits(const coclr_pool_desc* d, int* fits);
 /* aten::adaptive_avg_pool3d(x, (1,1,1)) and its backward; planes = N*C. */
 int coclr_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t S, void* stream);
 int coclr_global_avgpool_bwd(const float* dy, float* dx, int64_t planes, int64_t S, void* stream);

@@ -162,7 +162,8 @@ def test_adam_patch_and_cpu_fallthrough():
     product path) run torch's own implementation unchanged, state-dict format included."""
     import model.pretrain  # noqa: F401  (installs the subclass)
     from coclr_amd import optim as O
-    assert torch.optim.Adam is O.Adam and issubclass(O.Adam, O._TorchAdam)
+    assert torch.optim.Adam is O.ScopedAdam and issubclass(O.ScopedAdam, O.Adam) and \
+        issubclass(O.Adam, O._TorchAdam)
     g = load_golden("next_adam")
     ps = [p.clone().requires_grad_(True) for p in g["p0"]]
     opt = torch.optim.Adam([{"params": p} for p in ps], lr=g["lr"], weight_decay=g["wd"])
@@ -174,6 +175,12 @@ def test_adam_patch_and_cpu_fallthrough():
             assert torch.equal(p.detach(), ref)
     sd = opt.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and len(sd["param_groups"]) == 4
+    # scope of the process-wide alias: parameters of nobody's registered module never reach the kernel
+    assert opt._ours is False and opt._plan is None
+    assert O.Adam([torch.nn.Parameter(torch.zeros(2))])._scoped is False
+    m = model.pretrain.InfoNCE('s3d', 128, 32, 0.999, 0.07)
+    own = torch.optim.Adam([{"params": p} for p in m.parameters()], lr=1e-3)
+    assert O._owns_any(p for g_ in own.param_groups for p in g_["params"])
 
 
 def test_classifier_host_logic_matches_reference(fake):
@@ -284,11 +291,11 @@ def test_gradients_are_written_into_ddp_buckets(fake, monkeypatch):
                         n += 1
                 aliased.append(n)
                 opt.step()
-            return [p.detach().clone() for p in model.parameters()], aliased, model
+            return [p.detach().clone() for p in model.parameters()], aliased, (model, ddp)
 
         ref, _, _ = run(False)
         assert not engine._GRAD_SLOTS
-        got, aliased, model = run(True)
+        got, aliased, (model, ddp) = run(True)
         nparams = len(list(model.encoder_q[0].parameters()))
         # step 0 publishes the first buckets, DDP rebuilds them once after it, step 1 publishes the
         # rebuilt ones: from step 2 on every backbone gradient is produced in place
@@ -303,6 +310,11 @@ def test_gradients_are_written_into_ddp_buckets(fake, monkeypatch):
         p.grad = None
         assert run_.grad_out(p).data_ptr() == engine._GRAD_SLOTS[id(p)][1].data_ptr()
         assert run_.grad_out(p).data_ptr() != engine._GRAD_SLOTS[id(p)][1].data_ptr()   # once per run
+        # the slots belong to the wrapper: dropping it releases them (and the bucket storage they view)
+        del ddp, run_
+        import gc
+        gc.collect()
+        assert id(p) not in engine._GRAD_SLOTS
     finally:
         engine._GRAD_SLOTS.clear()
         if own:
