@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -30,6 +30,29 @@ class PoolDesc(C.Structure):
         "st", "sh", "sw", "pt", "ph", "pw")] + [("x_nstride", i64), ("y_nstride", i64)]
 
 
+class ConvCall(C.Structure):
+    """Mirror of `coclr_conv_call` (one problem of coclr_conv3d_fwd_multi)."""
+    _fields_ = [("d", C.POINTER(ConvDesc)), ("x", vp), ("w_packed", vp), ("y", vp), ("stats", vp),
+                ("bias", vp), ("ep_scale", vp), ("ep_shift", vp), ("n_index", vp), ("relu", i32),
+                ("accumulate", i32)]
+
+
+class BnFwdCall(C.Structure):
+    """Mirror of `coclr_bn_fwd_call`."""
+    _fields_ = [(n, vp) for n in ("sum", "sumsq", "gamma", "beta", "running_mean", "running_var",
+                                  "num_batches_tracked", "mean", "invstd", "scale", "shift", "y", "z")] + [
+        ("count", f64), ("S", i64), ("y_nstride", i64), ("z_nstride", i64), ("C", i32), ("ntiles", i32),
+        ("N", i32), ("relu", i32), ("momentum", f32), ("eps", f32)]
+
+
+class BnBwdCall(C.Structure):
+    """Mirror of `coclr_bn_bwd_call`."""
+    _fields_ = [(n, vp) for n in ("dz", "y", "scale", "shift", "mean", "invstd", "sums_ws", "dy", "dgamma",
+                                  "dbeta")] + [
+        ("S", i64), ("dz_nstride", i64), ("y_nstride", i64), ("dy_nstride", i64), ("N", i32), ("C", i32),
+        ("relu", i32), ("training", i32)]
+
+
 _P = C.POINTER
 _SIGNATURES = {
     "coclr_abi_version": [],
@@ -40,12 +63,15 @@ _SIGNATURES = {
     "coclr_conv_pack_batch": [vp, vp, i32, vp],
     "coclr_conv3d_ntiles": [_P(ConvDesc), _P(i32)],
     "coclr_conv3d_fwd": [_P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "coclr_conv3d_fwd_multi": [_P(ConvCall), i32, vp],
     "coclr_conv3d_wgrad_workspace": [_P(ConvDesc), _P(i64)],
     "coclr_conv3d_wgrad": [_P(ConvDesc), vp, vp, vp, vp, i64, i64, i32, i32, vp],
     "coclr_conv3d_wgrad_multi": [_P(ConvDesc), vp, vp, vp, vp, i32, vp, i64, i64, i32, i32, vp],
     "coclr_bn_finalize": [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp],
     "coclr_bn_finalize_apply": [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
                                 vp, vp, i32, i64, i64, i64, i32, vp],
+    "coclr_bn_finalize_apply_multi": [_P(BnFwdCall), i32, vp],
+    "coclr_bn_act_backward_multi": [_P(BnBwdCall), i32, vp],
     "coclr_bn_eval_affine": [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp],
     "coclr_bn_act_apply": [vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i64, i32, vp],
     "coclr_bn_backward_workspace": [i32, i32, _P(i64)],

@@ -94,6 +94,12 @@ class STConv3d(_Emitter):
         mid = engine.conv_bn_act(run, x, self.conv1, self.bn1, relu=True, n_index=n_index)
         return engine.conv_bn_act(run, mid, self.conv2, self.bn2, relu=True, out=out)
 
+    def _emit_gen(self, run, x, out=None):
+        """The same two units as a coroutine of launch requests (engine.drive_pair runs two of them in
+        lockstep: the branch1 / branch2 tails of an inception block)."""
+        mid = yield from engine.conv_bn_act_gen(run, x, self.conv1, self.bn1, relu=True)
+        return (yield from engine.conv_bn_act_gen(run, mid, self.conv2, self.bn2, relu=True, out=out))
+
 
 class SelfGating(_Emitter):
     def __init__(self, input_dim):
@@ -172,6 +178,13 @@ class SepInception(_Emitter):
         tails = (None, self.branch1[1], self.branch2[1])
         if self.gating:
             getattr(self, "gating_b0")._emit(run, heads[0], out=dst[0])
+        if engine.PAIR_UNITS and not self.gating and not run.lanes_on:
+            # the separable tails of branch 1 and branch 2 share every stencil shape: emitted in lockstep,
+            # their convolutions / BatchNorm passes / data gradients run as one launch each
+            engine.drive_pair(run, tails[1]._emit_gen(run, heads[1], out=dst[1]),
+                              tails[2]._emit_gen(run, heads[2], out=dst[2]))
+            self.branch3._emit(run, x, out=dst[3])
+            return engine.Val(block)
         # the separable tails of branch 1 / 2 and the pool branch are independent of each other:
         # one lane (HIP stream) each, joined before the block output is consumed
         for i in (1, 2, 3):

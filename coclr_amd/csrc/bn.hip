@@ -266,16 +266,15 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
 
 // forward: fold the conv's partial sums, coefficients + running statistics, then z = act(y*sc+sf)
 template <bool VEC>
-__global__ void __launch_bounds__(256)
-bn_fwd_fused_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int ntiles,
-                    double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                    float momentum, float eps, float* mean_out, float* invstd_out, float* scale_out,
-                    float* shift_out, const float* __restrict__ y, float* z, int N, int S,
-                    long y_nstride, long z_nstride, int relu) {
+__device__ __forceinline__ void
+bn_fwd_fused_body(const int c, const float* __restrict__ sum, const float* __restrict__ sumsq, int ntiles,
+                  double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                  float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                  float momentum, float eps, float* mean_out, float* invstd_out, float* scale_out,
+                  float* shift_out, const float* __restrict__ y, float* z, int N, int S,
+                  long y_nstride, long z_nstride, int relu) {
   __shared__ double red[4];
   __shared__ float coef[2];
-  const int c = blockIdx.x;
   const float* ps = sum + (long)c * ntiles;
   const float* pq = sumsq + (long)c * ntiles;
   double s = 0.0, q = 0.0;
@@ -342,17 +341,67 @@ bn_fwd_fused_kernel(const float* __restrict__ sum, const float* __restrict__ sum
   }
 }
 
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_fwd_fused_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int ntiles,
+                    double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, float* mean_out, float* invstd_out, float* scale_out,
+                    float* shift_out, const float* __restrict__ y, float* z, int N, int S,
+                    long y_nstride, long z_nstride, int relu) {
+  bn_fwd_fused_body<VEC>((int)blockIdx.x, sum, sumsq, ntiles, count, gamma, beta, running_mean, running_var,
+                         num_batches_tracked, momentum, eps, mean_out, invstd_out, scale_out, shift_out, y,
+                         z, N, S, y_nstride, z_nstride, relu);
+}
+
+// Up to four BatchNorm units in ONE launch (the three 1x1x1 heads of an inception block; the two
+// separable branches side by side): the grid is the units' channels back to back, a workgroup finds its
+// unit by its index.  Same body, same arithmetic, same results as the single-unit launches.
+struct BnFwdUnit {
+  const float* sum; const float* sumsq; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* nbt;
+  float* mean; float* invstd; float* scale; float* shift;
+  const float* y; float* z;
+  double count;
+  long y_nstride, z_nstride;
+  int C, ntiles, N, S, relu;
+  float momentum, eps;
+};
+struct BnFwdTable { BnFwdUnit u[4]; int n; };
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_fwd_fused_multi_kernel(const BnFwdTable t) {
+  int c = (int)blockIdx.x;
+#define COCLR_BN_FWD_UNIT(k)                                                                              \
+  if (k < t.n) {                                                                                         \
+    if (c < t.u[k].C) {                                                                                  \
+      bn_fwd_fused_body<VEC>(c, t.u[k].sum, t.u[k].sumsq, t.u[k].ntiles, t.u[k].count, t.u[k].gamma,     \
+                             t.u[k].beta, t.u[k].running_mean, t.u[k].running_var, t.u[k].nbt,           \
+                             t.u[k].momentum, t.u[k].eps, t.u[k].mean, t.u[k].invstd, t.u[k].scale,      \
+                             t.u[k].shift, t.u[k].y, t.u[k].z, t.u[k].N, t.u[k].S, t.u[k].y_nstride,     \
+                             t.u[k].z_nstride, t.u[k].relu);                                             \
+      return;                                                                                            \
+    }                                                                                                    \
+    c -= t.u[k].C;                                                                                       \
+  }
+  COCLR_BN_FWD_UNIT(0)
+  COCLR_BN_FWD_UNIT(1)
+  COCLR_BN_FWD_UNIT(2)
+  COCLR_BN_FWD_UNIT(3)
+#undef COCLR_BN_FWD_UNIT
+}
+
 // backward: sums of g and g*xhat over the channel, then dy = A*g + B*y + D (training) / scale*g
 // (eval); the second read of dz / y comes out of L2 (<= 128 KB per workgroup).
 template <bool VEC>
-__global__ void __launch_bounds__(256)
-bn_bwd_fused_kernel(const float* __restrict__ dz, const float* __restrict__ y,
-                    const float* __restrict__ scale, const float* __restrict__ shift,
-                    const float* __restrict__ mean, const float* __restrict__ invstd, int training,
-                    float* dgamma, float* dbeta, float* dy, int N, int S, long dz_nstride,
-                    long y_nstride, long dy_nstride, int relu) {
+__device__ __forceinline__ void
+bn_bwd_fused_body(const int c, const float* __restrict__ dz, const float* __restrict__ y,
+                  const float* __restrict__ scale, const float* __restrict__ shift,
+                  const float* __restrict__ mean, const float* __restrict__ invstd, int training,
+                  float* dgamma, float* dbeta, float* dy, int N, int S, long dz_nstride,
+                  long y_nstride, long dy_nstride, int relu) {
   __shared__ double red[4];
-  const int c = blockIdx.x;
   const float sc = scale[c], sf = shift[c], mu = mean[c], is = invstd[c];
   double sg = 0.0, sgx = 0.0;
   if (VEC) {
@@ -455,6 +504,48 @@ bn_bwd_fused_kernel(const float* __restrict__ dz, const float* __restrict__ y,
   }
 }
 
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_bwd_fused_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                    const float* __restrict__ scale, const float* __restrict__ shift,
+                    const float* __restrict__ mean, const float* __restrict__ invstd, int training,
+                    float* dgamma, float* dbeta, float* dy, int N, int S, long dz_nstride,
+                    long y_nstride, long dy_nstride, int relu) {
+  bn_bwd_fused_body<VEC>((int)blockIdx.x, dz, y, scale, shift, mean, invstd, training, dgamma, dbeta, dy, N, S,
+                         dz_nstride, y_nstride, dy_nstride, relu);
+}
+
+struct BnBwdUnit {
+  const float* dz; const float* y; const float* scale; const float* shift; const float* mean;
+  const float* invstd;
+  float* dgamma; float* dbeta; float* dy;
+  long dz_nstride, y_nstride, dy_nstride;
+  int C, N, S, relu, training;
+};
+struct BnBwdTable { BnBwdUnit u[4]; int n; };
+
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_bwd_fused_multi_kernel(const BnBwdTable t) {
+  int c = (int)blockIdx.x;
+#define COCLR_BN_BWD_UNIT(k)                                                                              \
+  if (k < t.n) {                                                                                         \
+    if (c < t.u[k].C) {                                                                                  \
+      bn_bwd_fused_body<VEC>(c, t.u[k].dz, t.u[k].y, t.u[k].scale, t.u[k].shift, t.u[k].mean,            \
+                             t.u[k].invstd, t.u[k].training, t.u[k].dgamma, t.u[k].dbeta, t.u[k].dy,     \
+                             t.u[k].N, t.u[k].S, t.u[k].dz_nstride, t.u[k].y_nstride,                    \
+                             t.u[k].dy_nstride, t.u[k].relu);                                            \
+      return;                                                                                            \
+    }                                                                                                    \
+    c -= t.u[k].C;                                                                                       \
+  }
+  COCLR_BN_BWD_UNIT(0)
+  COCLR_BN_BWD_UNIT(1)
+  COCLR_BN_BWD_UNIT(2)
+  COCLR_BN_BWD_UNIT(3)
+#undef COCLR_BN_BWD_UNIT
+}
+
 constexpr long kSmallChannel = 32768;     // N*S per channel up to which one workgroup per channel wins
 
 // Grid for the streaming kernels: x = chunks of one plane, y = (sample groups) x C.
@@ -527,6 +618,57 @@ extern "C" int coclr_bn_finalize_apply(const float* sum, const float* sumsq, int
                        eps, mean, invstd, scale, shift, y, z, N, (int)S, (long)y_nstride,
                        (long)z_nstride, relu);
   COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_bn_finalize_apply_multi(const coclr_bn_fwd_call* calls, int n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!calls || n < 1) return COCLR_EINVAL;
+  const char* env = getenv("COCLR_PAIR");
+  const bool fuse = !(env && env[0] == '0');
+  int i = 0;
+  while (i < n) {
+    // a run of up to four small units (one workgroup per channel) with the same vector width
+    BnFwdTable t;
+    t.n = 0;
+    long blocks = 0;
+    bool vec0 = false;
+    int j = i;
+    for (; j < n && t.n < 4; ++j) {
+      const coclr_bn_fwd_call& c = calls[j];
+      if (c.C <= 0 || c.ntiles <= 0 || c.N <= 0 || c.S <= 0 || !c.y || !c.z) return COCLR_EINVAL;
+      const bool small = (long)c.N * c.S <= kSmallChannel;
+      const bool vec = (c.S % 4 == 0) && (c.y_nstride % 4 == 0) && (c.z_nstride % 4 == 0);
+      if (!small || !fuse) break;
+      if (t.n == 0) vec0 = vec;
+      else if (vec != vec0) break;
+      BnFwdUnit& u = t.u[t.n++];
+      u.sum = c.sum; u.sumsq = c.sumsq; u.gamma = c.gamma; u.beta = c.beta;
+      u.running_mean = c.running_mean; u.running_var = c.running_var; u.nbt = c.num_batches_tracked;
+      u.mean = c.mean; u.invstd = c.invstd; u.scale = c.scale; u.shift = c.shift;
+      u.y = c.y; u.z = c.z; u.count = c.count;
+      u.y_nstride = (long)c.y_nstride; u.z_nstride = (long)c.z_nstride;
+      u.C = c.C; u.ntiles = c.ntiles; u.N = c.N; u.S = (int)c.S; u.relu = c.relu;
+      u.momentum = c.momentum; u.eps = c.eps;
+      blocks += c.C;
+    }
+    if (t.n >= 2) {
+      if (vec0)
+        hipLaunchKernelGGL(bn_fwd_fused_multi_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+      else
+        hipLaunchKernelGGL(bn_fwd_fused_multi_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+      COCLR_LAUNCH_CHECK();
+      i = j;
+      continue;
+    }
+    const coclr_bn_fwd_call& c = calls[i];
+    int rc = coclr_bn_finalize_apply(c.sum, c.sumsq, c.C, c.ntiles, c.count, c.gamma, c.beta,
+                                     c.running_mean, c.running_var, c.num_batches_tracked, c.momentum,
+                                     c.eps, c.mean, c.invstd, c.scale, c.shift, c.y, c.z, c.N, c.S,
+                                     c.y_nstride, c.z_nstride, c.relu, stream_);
+    if (rc) return rc;
+    ++i;
+  }
   return 0;
 }
 
@@ -617,5 +759,52 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
                        N, C, (int)S, (long)dz_nstride, (long)y_nstride, (long)dy_nstride,
                        (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
   COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_bn_act_backward_multi(const coclr_bn_bwd_call* calls, int n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!calls || n < 1) return COCLR_EINVAL;
+  const char* env = getenv("COCLR_PAIR");
+  const bool fuse = !(env && env[0] == '0');
+  int i = 0;
+  while (i < n) {
+    BnBwdTable t;
+    t.n = 0;
+    long blocks = 0;
+    bool vec0 = false;
+    int j = i;
+    for (; j < n && t.n < 4; ++j) {
+      const coclr_bn_bwd_call& c = calls[j];
+      if (c.N <= 0 || c.C <= 0 || c.S <= 0 || !c.dz || !c.y || !c.dy) return COCLR_EINVAL;
+      const bool small = (long)c.N * c.S <= kSmallChannel;
+      const bool vec = (c.S % 4 == 0) && (c.dz_nstride % 4 == 0) && (c.y_nstride % 4 == 0) &&
+                       (c.dy_nstride % 4 == 0);
+      if (!small || !fuse) break;
+      if (t.n == 0) vec0 = vec;
+      else if (vec != vec0) break;
+      BnBwdUnit& u = t.u[t.n++];
+      u.dz = c.dz; u.y = c.y; u.scale = c.scale; u.shift = c.shift; u.mean = c.mean; u.invstd = c.invstd;
+      u.dgamma = c.dgamma; u.dbeta = c.dbeta; u.dy = c.dy;
+      u.dz_nstride = (long)c.dz_nstride; u.y_nstride = (long)c.y_nstride; u.dy_nstride = (long)c.dy_nstride;
+      u.C = c.C; u.N = c.N; u.S = (int)c.S; u.relu = c.relu; u.training = c.training;
+      blocks += c.C;
+    }
+    if (t.n >= 2) {
+      if (vec0)
+        hipLaunchKernelGGL(bn_bwd_fused_multi_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+      else
+        hipLaunchKernelGGL(bn_bwd_fused_multi_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+      COCLR_LAUNCH_CHECK();
+      i = j;
+      continue;
+    }
+    const coclr_bn_bwd_call& c = calls[i];
+    int rc = coclr_bn_act_backward(c.dz, c.y, nullptr, c.scale, c.shift, c.mean, c.invstd, c.sums_ws, c.dy,
+                                   nullptr, c.dgamma, c.dbeta, c.N, c.C, c.S, c.dz_nstride, c.y_nstride,
+                                   c.dy_nstride, 0, 0, c.relu, c.training, 0, stream_);
+    if (rc) return rc;
+    ++i;
+  }
   return 0;
 }

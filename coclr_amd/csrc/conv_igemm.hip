@@ -1708,15 +1708,15 @@ inline int granule_count(const ConvPlan& p) {
 
 // A launch that coclr_conv3d_fwd_multi may fuse with its neighbour: the launcher fills the slot instead of
 // launching; two slots with the same `pair` function are the same kernel variant.
+typedef int (*SingleFn)(const ConvArgs&, long, size_t, hipStream_t);
+typedef int (*PairFn)(const ConvArgs&, const ConvArgs&, long, long, size_t, hipStream_t);
 struct PairSlot {
   ConvArgs args;
   long blocks;
   size_t lds;
-  int (*single)(const ConvArgs&, long, size_t, hipStream_t);
-  int (*pair)(const ConvArgs&, const ConvArgs&, long, long, size_t, hipStream_t);
+  SingleFn single;
+  PairFn pair;
   bool pending;
-  // tile choice of a (1,3,3) direct launch, so that the second problem of a pair can be planned with it
-  int bm, lbn;
 };
 
 template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4, bool XG>
@@ -1737,6 +1737,36 @@ int variant_pair(const ConvArgs& a0, const ConvArgs& a1, long b0, long b1, size_
   hipLaunchKernelGGL(kern, dim3((unsigned)(b0 + b1)), dim3(256), lds, stream, a0, a1, (int)b0);
   COCLR_LAUNCH_CHECK();
   return 0;
+}
+
+// Two DIFFERENT variants of the (1,3,3) small-map kernel in one launch: on the first 8x8x8 blocks the wide
+// branch takes 64x128 tiles and the narrow one 64x64 (choose_tile); each problem keeps its own plan, so
+// outputs and statistics are bit-identical to the two single launches.
+template <int BNA, int BNB>
+__global__ void __launch_bounds__(256)
+conv_igemm_133_mixed_kernel(const ConvArgs a0, const ConvArgs a1, const int nb0) {
+  if ((int)blockIdx.x < nb0)
+    conv_igemm_body<1, 3, 3, 8, 64, BNA, 3, false, true>(a0, (int)blockIdx.x, nb0);
+  else
+    conv_igemm_body<1, 3, 3, 8, 64, BNB, 3, false, true>(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+}
+
+template <int BNA, int BNB>
+int mixed_pair_launch(const ConvArgs& a0, const ConvArgs& a1, long b0, long b1, size_t lds, hipStream_t stream) {
+  auto kern = conv_igemm_133_mixed_kernel<BNA, BNB>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b0 + b1)), dim3(256), lds, stream, a0, a1, (int)b0);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+inline PairFn mixed_pair(SingleFn f0, SingleFn f1) {
+  const SingleFn wide = &variant_single<1, 3, 3, 8, 64, 128, 3, false, true>;
+  const SingleFn narrow = &variant_single<1, 3, 3, 8, 64, 64, 3, false, true>;
+  if (f0 == wide && f1 == narrow) return &mixed_pair_launch<128, 64>;
+  if (f0 == narrow && f1 == wide) return &mixed_pair_launch<64, 128>;
+  return nullptr;
 }
 
 template <int KT, int KH, int KW, int CC, int BM, int BN, int PCH, bool XV4 = false, bool XG = false>
@@ -1928,8 +1958,7 @@ extern "C" int coclr_conv_pack_batch(const int64_t* table, const int32_t* blockm
 namespace {
 
 // Fill plan + pick variant.  Returns 0 and the variant id, or an error.
-int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant, const Choice* force = nullptr,
-                 Choice* chosen = nullptr) {
+int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
   if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return COCLR_EINVAL;
   conv_normalise(d, p);
   const int kt = d->kt, kh = d->kh, kw = d->kw;
@@ -1958,13 +1987,6 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant, const Choi
     *variant = 60;
   } else if (kt == 1 && kh == 3 && kw == 3) {
     c = choose_tile(*p, 1, 3, 3, true, true, 256, 512);
-    if (force) {
-      // second problem of a pair: the first one's tile, when this geometry can take it
-      ConvPlan q = *p;
-      conv_pick_box(&q, force->lbn, 1, 3, 3);
-      if (q.plane <= (force->lbn == 6 ? 512 : 256)) c = *force;
-    }
-    if (chosen) *chosen = c;
     conv_pick_box(p, c.lbn, 1, 3, 3);
     if (c.lbn == 6) *variant = p->plane <= 256 ? 12 : 13;
     else *variant = c.bm == 128 ? 10 : 11;
@@ -2016,17 +2038,15 @@ extern "C" int coclr_conv3d_ntiles(const coclr_conv_desc* d, int* ntiles) {
 namespace {
 
 // The launch behind coclr_conv3d_fwd.  With `slot`, variants that have a pair kernel fill it instead of
-// launching (see PairSlot); `force` plans a (1,3,3) direct problem with a given tile.
+// launching (see PairSlot).
 int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_packed, float* y,
                     float* stats, const float* bias, const float* ep_scale, const float* ep_shift,
                     const int64_t* n_index, int relu, int accumulate, hipStream_t stream,
-                    PairSlot* slot, const Choice* force) {
+                    PairSlot* slot) {
   ConvPlan p;
   int variant;
-  Choice chosen{0, 0};
-  int rc = plan_forward(d, &p, &variant, force, &chosen);
+  int rc = plan_forward(d, &p, &variant);
   if (rc) return rc;
-  if (slot) { slot->bm = chosen.bm; slot->lbn = chosen.lbn; }
   ConvArgs a;
   a.x = x; a.w = w_packed; a.y = y; a.stats = stats; a.bias = bias;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.n_index = n_index;
@@ -2176,7 +2196,7 @@ extern "C" int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const 
                                 const float* ep_shift, const int64_t* n_index, int relu,
                                 int accumulate, void* stream) {
   return conv3d_fwd_impl(d, x, w_packed, y, stats, bias, ep_scale, ep_shift, n_index, relu, accumulate,
-                         (hipStream_t)stream, nullptr, nullptr);
+                         (hipStream_t)stream, nullptr);
 }
 
 namespace {
@@ -2186,25 +2206,6 @@ inline bool pair_enabled() {
   return !(env && env[0] == '0');
 }
 }  // namespace
-
-extern "C" int coclr_conv3d_multi_ntiles(const coclr_conv_desc* const* descs, int n, int* ntiles) {
-  if (!descs || !ntiles || n < 1) return COCLR_EINVAL;
-  const bool fuse = pair_enabled();
-  for (int i = 0; i < n; i += 2) {
-    ConvPlan p;
-    int v;
-    Choice c0{0, 0};
-    int rc = plan_forward(descs[i], &p, &v, nullptr, &c0);
-    if (rc) return rc;
-    ntiles[i] = p.ntiles;
-    if (i + 1 < n) {
-      rc = plan_forward(descs[i + 1], &p, &v, fuse && c0.bm ? &c0 : nullptr, nullptr);
-      if (rc) return rc;
-      ntiles[i + 1] = p.ntiles;
-    }
-  }
-  return 0;
-}
 
 extern "C" int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -2216,7 +2217,7 @@ extern "C" int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void*
       for (int j = i; j < n && j < i + 2; ++j) {
         const coclr_conv_call& c = calls[j];
         int rc = conv3d_fwd_impl(c.d, c.x, c.w_packed, c.y, c.stats, c.bias, c.ep_scale, c.ep_shift,
-                                 c.n_index, c.relu, c.accumulate, stream, nullptr, nullptr);
+                                 c.n_index, c.relu, c.accumulate, stream, nullptr);
         if (rc) return rc;
       }
       continue;
@@ -2225,16 +2226,17 @@ extern "C" int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void*
     PairSlot s0, s1;
     s0.pending = s1.pending = false;
     s0.pair = s1.pair = nullptr;
-    s0.bm = s1.bm = 0;
+    s0.single = s1.single = nullptr;
     int rc = conv3d_fwd_impl(c0.d, c0.x, c0.w_packed, c0.y, c0.stats, c0.bias, c0.ep_scale, c0.ep_shift,
-                             c0.n_index, c0.relu, c0.accumulate, stream, &s0, nullptr);
+                             c0.n_index, c0.relu, c0.accumulate, stream, &s0);
     if (rc) return rc;
-    const Choice force{s0.bm, s0.lbn};
     rc = conv3d_fwd_impl(c1.d, c1.x, c1.w_packed, c1.y, c1.stats, c1.bias, c1.ep_scale, c1.ep_shift,
-                         c1.n_index, c1.relu, c1.accumulate, stream, &s1, s0.bm ? &force : nullptr);
+                         c1.n_index, c1.relu, c1.accumulate, stream, &s1);
     if (rc) return rc;
-    if (s0.pending && s1.pending && s0.pair && s0.pair == s1.pair) {
-      rc = s0.pair(s0.args, s1.args, s0.blocks, s1.blocks, s0.lds > s1.lds ? s0.lds : s1.lds, stream);
+    PairFn fused = nullptr;
+    if (s0.pending && s1.pending) fused = s0.single == s1.single ? s0.pair : mixed_pair(s0.single, s1.single);
+    if (fused) {
+      rc = fused(s0.args, s1.args, s0.blocks, s1.blocks, s0.lds > s1.lds ? s0.lds : s1.lds, stream);
       if (rc) return rc;
     } else {
       if (s0.pending) { rc = s0.single(s0.args, s0.blocks, s0.lds, stream); if (rc) return rc; }

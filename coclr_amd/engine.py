@@ -367,7 +367,7 @@ class Run:
                     for st in started.values():
                         cur.wait_stream(st)
                     started = {}
-                fn(self)
+                _run_closure(fn, self)
             else:
                 st = started.get(lane)
                 if st is None:
@@ -375,7 +375,7 @@ class Run:
                     st.wait_stream(parent)
                     started[lane] = st
                 with torch.cuda.stream(st):
-                    fn(self)
+                    _run_closure(fn, self)
         if started:
             cur = torch.cuda.current_stream(self.device)
             for st in started.values():
@@ -530,8 +530,153 @@ def _is_plain_pointwise(k, s):
     return k == (1, 1, 1) and s != (1, 1, 1)
 
 
+# ---------------------------------------------------------------------------------
+# Units as coroutines: sibling units in lockstep, their launches fused pairwise
+# ---------------------------------------------------------------------------------
+# A conv unit (conv_bn_act) is written as a generator that YIELDS its main-stream launches as requests
+#   ("conv", {...})    forward convolution or data gradient      -> (statistics buffer, slots per channel)
+#   ("bn_fwd", {...})  BatchNorm finalize + apply (+ReLU)
+#   ("bn_bwd", {...})  BatchNorm(+ReLU) backward
+# instead of calling ops directly.  Driven alone (`_drive`) every request is executed at once: the launch
+# sequence is exactly what direct calls would give.  Two INDEPENDENT units with the same structure -- the
+# separable branch1 / branch2 tails of an inception block (backbone/s3dg.py:100-118) -- are driven in
+# lockstep (`drive_pair`): requests of the same kind become ONE call of the library's multi entry points
+# (coclr_conv3d_fwd_multi, coclr_bn_finalize_apply_multi, coclr_bn_act_backward_multi), which launch both
+# problems as one grid where the kernels allow it.  The backward closures the two units record are
+# generators as well and are paired on the tape, so the backward pass fuses the same way.  Weight gradients
+# (side stream, nothing waits for them) are not requests.
+PAIR_UNITS = os.environ.get("COCLR_PAIR_UNITS", "1") != "0"
+
+
+def _exec(req):
+    kind, c = req
+    if kind == "conv":
+        stats = nt = None
+        if c.get("want_stats"):
+            nt = c["geom"].ntiles()
+            stats = torch.empty(2 * c["geom"].Cout * nt, dtype=torch.float32, device=c["y"].device)
+        ops.conv_fwd(c["geom"], c["x"], c["w"], c["y"], stats=stats, n_index=c.get("n_index"),
+                     accumulate=c.get("accumulate", False))
+        return stats, nt
+    if kind == "bn_fwd":
+        gamma, beta, rm, rv, nbt, momentum, eps = c["bn"]
+        mean, invstd, scale, shift = c["small"]
+        ops.bn_finalize_apply(c["stats"], c["C"], c["ntiles"], c["count"], gamma, beta, rm, rv, nbt, momentum,
+                              eps, mean, invstd, scale, shift, c["y"], c["z"], c["relu"], c0=c.get("c0", 0),
+                              c_total=c.get("c_total"))
+        return None
+    if kind == "bn_bwd":
+        ops.bn_act_backward(c["dz"], c["y"], None, c["scale"], c["shift"], c["mean"], c["invstd"], c["sums"],
+                            c["dy"], None, c["dgamma"], c["dbeta"], c["relu"], c["training"])
+        return None
+    raise RuntimeError("coclr_amd: unknown launch request %r" % (kind,))
+
+
+def _exec_pair(ra, rb):
+    kind = ra[0]
+    if kind != rb[0]:
+        return _exec(ra), _exec(rb)
+    ca, cb = ra[1], rb[1]
+    if kind == "conv":
+        res = [(None, None), (None, None)]
+        for i, c in enumerate((ca, cb)):
+            if c.get("want_stats"):
+                nt = c["geom"].ntiles()
+                c["stats"] = torch.empty(2 * c["geom"].Cout * nt, dtype=torch.float32, device=c["y"].device)
+                res[i] = (c["stats"], nt)
+        ops.conv_fwd_multi([ca, cb])
+        return res[0], res[1]
+    if kind == "bn_fwd":
+        ops.bn_finalize_apply_multi([ca, cb])
+        return None, None
+    if kind == "bn_bwd":
+        ops.bn_act_backward_multi([ca, cb])
+        return None, None
+    return _exec(ra), _exec(rb)
+
+
+def _drive(gen):
+    """Run a unit coroutine alone: every request is executed when it is made."""
+    try:
+        req = next(gen)
+        while True:
+            req = gen.send(_exec(req))
+    except StopIteration as e:
+        return e.value
+
+
+def _run_closure(fn, run):
+    """A tape entry: a plain function, or a generator function whose requests are executed one by one."""
+    r = fn(run)
+    if r is not None and hasattr(r, "send"):
+        _drive(r)
+
+
+class _PairedBackward:
+    """Tape entry for two units emitted in lockstep: their backward coroutines run in lockstep too."""
+    __slots__ = ("fa", "fb")
+
+    def __init__(self, fa, fb):
+        self.fa, self.fb = fa, fb
+
+    def __call__(self, run):
+        ga, gb = self.fa(run), self.fb(run)
+        ga = ga if ga is not None and hasattr(ga, "send") else None
+        gb = gb if gb is not None and hasattr(gb, "send") else None
+        if ga is not None and gb is not None:
+            drive_pair(run, ga, gb)
+        else:
+            for g in (ga, gb):
+                if g is not None:
+                    _drive(g)
+
+
+def drive_pair(run, ga, gb):
+    """Run two unit coroutines in lockstep, fusing requests of the same kind; returns their values.
+    Closures they record on the run's tape are collected per unit and appended as paired entries."""
+    main_tape = run.tape
+    tapes = ([], [])
+    gens = [ga, gb]
+    reqs, vals, done = [None, None], [None, None], [False, False]
+
+    def advance(i, first, value=None):
+        run.tape = tapes[i]
+        try:
+            reqs[i] = next(gens[i]) if first else gens[i].send(value)
+        except StopIteration as e:
+            done[i], vals[i], reqs[i] = True, e.value, None
+        finally:
+            run.tape = main_tape
+
+    advance(0, True)
+    advance(1, True)
+    while not (done[0] and done[1]):
+        if not done[0] and not done[1]:
+            ra, rb = _exec_pair(reqs[0], reqs[1])
+            advance(0, False, ra)
+            advance(1, False, rb)
+        else:
+            i = 0 if not done[0] else 1
+            advance(i, False, _exec(reqs[i]))
+    ta, tb = tapes
+    for i in range(max(len(ta), len(tb))):
+        if i < len(ta) and i < len(tb) and ta[i][1] is None and tb[i][1] is None:
+            main_tape.append((_PairedBackward(ta[i][0], tb[i][0]), None))
+        else:
+            if i < len(ta):
+                main_tape.append(ta[i])
+            if i < len(tb):
+                main_tape.append(tb[i])
+    return vals[0], vals[1]
+
+
 def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=None):
-    """One conv unit of the backbone.
+    """One conv unit of the backbone, executed at once (see conv_bn_act_gen)."""
+    return _drive(conv_bn_act_gen(run, x, conv, bn, relu=relu, out=out, residual=residual, n_index=n_index))
+
+
+def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_index=None):
+    """One conv unit of the backbone, as a coroutine of launch requests (see above).
 
     x: Val.  conv: nn.Conv3d (bias-free) holding the weight.  bn: nn.BatchNorm3d.
     out: optional Val (channel slice of a concat buffer) to receive the activation.
@@ -577,13 +722,13 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
     y = None
     if want_y:
         y = run.empty(N, Cout, *odim)
-        stats = None
+        stats = ntiles = None
         for t, g in enumerate(geoms):
             last = t == len(geoms) - 1
+            res = yield ("conv", dict(geom=g, x=xv, w=run.pack(w, False, t if sliced else None, algo=g.algo),
+                                      y=y, want_stats=training and last, n_index=n_index, accumulate=t > 0))
             if training and last:
-                stats = run.empty(2 * Cout * g.ntiles())
-            ops.conv_fwd(g, xv, run.pack(w, False, t if sliced else None, algo=g.algo), y,
-                         stats=stats if last else None, n_index=n_index, accumulate=t > 0)
+                stats, ntiles = res
         count = N * odim[0] * odim[1] * odim[2]
         lazy = LAZY_APPLY and residual is None and lazy_ok and count > ops.SMALL_CHANNEL
         if training:
@@ -591,12 +736,12 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                 raise NotImplementedError("coclr_amd: cumulative-average BatchNorm momentum")
             if residual is None and not lazy:
                 # statistics + apply in one call (a single launch for the small late-stage layers)
-                ops.bn_finalize_apply(stats, Cout, geoms[-1].ntiles(), count, bn.weight, bn.bias,
-                                      bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                      float(bn.momentum), float(bn.eps), mean, invstd, scale, shift,
-                                      y, zv, relu)
+                yield ("bn_fwd", dict(stats=stats, C=Cout, ntiles=ntiles, count=count,
+                                      bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                          bn.num_batches_tracked, float(bn.momentum), float(bn.eps)),
+                                      small=(mean, invstd, scale, shift), y=y, z=zv, relu=relu))
             else:
-                ops.bn_finalize(stats, Cout, geoms[-1].ntiles(), count, bn.weight, bn.bias,
+                ops.bn_finalize(stats, Cout, ntiles, count, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 float(bn.momentum), float(bn.eps), mean, invstd, scale, shift)
         else:
@@ -635,14 +780,18 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                 # (geometry, d(pool output), arg-max) here and d(activation) is never materialised
                 ops.bn_act_backward_pooled(pooled[0], pooled[1], pooled[2], y, scale, shift, mean,
                                            invstd, sums, dy, dgb[0], dgb[1], relu, training)
+            elif residual is None:
+                yield ("bn_bwd", dict(dz=run.grad_of(out), y=y, scale=scale, shift=shift, mean=mean,
+                                      invstd=invstd, sums=sums, dy=dy, dgamma=dgb[0], dbeta=dgb[1], relu=relu,
+                                      training=training))
             else:
                 dz = run.grad_of(out)
                 dres = None
                 dres_acc = False
-                if residual is not None and run.needs_grad(residual):
+                if run.needs_grad(residual):
                     dres, dres_acc = run.grad_target(residual)
-                ops.bn_act_backward(dz, y, zv if residual is not None else None, scale, shift, mean,
-                                    invstd, sums, dy, dres, dgb[0], dgb[1], relu, training, dres_acc)
+                ops.bn_act_backward(dz, y, zv, scale, shift, mean, invstd, sums, dy, dres, dgb[0], dgb[1],
+                                    relu, training, dres_acc)
             if bn.weight.requires_grad:
                 run.add_param_grad(bn.weight, dgb[0])
             if bn.bias.requires_grad:
@@ -668,7 +817,7 @@ def conv_bn_act(run, x, conv, bn, relu=True, out=None, residual=None, n_index=No
                                                       tap_step=step), dx, accumulate=acc)
                 else:
                     dg = geoms[0].dgrad()
-                    ops.conv_fwd(dg, dy, run.pack(w, True, algo=dg.algo), dx, accumulate=acc)
+                    yield ("conv", dict(geom=dg, x=dy, w=run.pack(w, True, algo=dg.algo), y=dx, accumulate=acc))
 
         run.record(backward)
     elif y is not None:
@@ -712,6 +861,7 @@ def pointwise_group(run, x, units):
     count = N * idim[0] * idim[1] * idim[2]
     outs, saved = [], []
     c0 = 0
+    fwd_units = []
     for (conv, bn, out), C_ in zip(units, widths):
         small = run.empty(4, C_)
         mean, invstd, scale, shift = small[0], small[1], small[2], small[3]
@@ -720,10 +870,11 @@ def pointwise_group(run, x, units):
                 raise NotImplementedError("coclr_amd: cumulative-average BatchNorm momentum")
             if out is None:
                 out = Val(run.empty(N, C_, *idim))
-            ops.bn_finalize_apply(stats, C_, ntiles, count, bn.weight, bn.bias, bn.running_mean,
-                                  bn.running_var, bn.num_batches_tracked, float(bn.momentum),
-                                  float(bn.eps), mean, invstd, scale, shift, y[:, c0:c0 + C_],
-                                  out.view(), True, c0=c0, c_total=Ccat)
+            fwd_units.append(dict(stats=stats, C=C_, ntiles=ntiles, count=count,
+                                  bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      bn.num_batches_tracked, float(bn.momentum), float(bn.eps)),
+                                  small=(mean, invstd, scale, shift), y=y[:, c0:c0 + C_], z=out.view(),
+                                  relu=True, c0=c0, c_total=Ccat))
         else:
             ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
                                C_, mean, invstd, scale, shift)
@@ -732,21 +883,29 @@ def pointwise_group(run, x, units):
             ops.bn_act_apply(y[:, c0:c0 + C_], scale, shift, None, out.view(), True)
         outs.append(out)
         saved.append((c0, C_, mean, invstd, scale, shift))
-        if run.save and DECISION_PROBE is not None:
-            _probe_relu(bn, y[:, c0:c0 + C_], scale, shift)
         c0 += C_
+    if fwd_units:
+        # the heads' BatchNorm units in one call (one launch on the 8x8x8 / 4x4x4 maps)
+        ops.bn_finalize_apply_multi(fwd_units)
+    if run.save and DECISION_PROBE is not None:
+        for (conv, bn, _), (c0_, C_, mean, invstd, scale, shift) in zip(units, saved):
+            _probe_relu(bn, y[:, c0_:c0_ + C_], scale, shift)
 
     if run.save:
         x_needs = run.needs_grad(x)
 
         def backward(run):
             dy = torch.empty_like(y)
+            bwd_units, dgbs = [], []
             for (conv, bn, _), out, (c0, C_, mean, invstd, scale, shift) in zip(units, outs, saved):
                 dgb = (run.grad_out(bn.weight), run.grad_out(bn.bias))
                 sums = run.empty(ops.bn_backward_workspace(N, C_), dtype=torch.float64)
-                ops.bn_act_backward(run.grad_of(out), y[:, c0:c0 + C_], None, scale, shift, mean,
-                                    invstd, sums, dy[:, c0:c0 + C_], None, dgb[0], dgb[1], True,
-                                    training)
+                bwd_units.append(dict(dz=run.grad_of(out), y=y[:, c0:c0 + C_], scale=scale, shift=shift,
+                                      mean=mean, invstd=invstd, sums=sums, dy=dy[:, c0:c0 + C_],
+                                      dgamma=dgb[0], dbeta=dgb[1], relu=True, training=training))
+                dgbs.append(dgb)
+            ops.bn_act_backward_multi(bwd_units)
+            for (conv, bn, _), dgb in zip(units, dgbs):
                 if bn.weight.requires_grad:
                     run.add_param_grad(bn.weight, dgb[0])
                 if bn.bias.requires_grad:

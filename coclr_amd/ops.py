@@ -12,7 +12,7 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, PoolDesc
+from ._lib import BnBwdCall, BnFwdCall, ConvCall, ConvDesc, PoolDesc
 
 
 _HANDLE = None
@@ -316,6 +316,33 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
         _p(n_index, torch.int64), int(relu), int(accumulate), _stream()), "conv3d_fwd", geom)
 
 
+def conv_fwd_multi(calls):
+    """Independent convolutions in one call (consecutive pairs of the same kernel variant in one launch).
+    calls: [dict(geom, x, w, y, stats=None, n_index=None, accumulate=False)]; every problem keeps the plan it
+    has alone (statistics: geom.ntiles() slots per channel)."""
+    n = len(calls)
+    arr = (ConvCall * n)()
+    descs = []
+    for i, c in enumerate(calls):
+        geom, x, y = c["geom"], c["x"], c["y"]
+        # every problem gets its OWN descriptor copy: two problems may share one cached geometry
+        d = type(geom.desc).from_buffer_copy(_desc(geom))
+        d.x_nstride = _chk5(x, "x")
+        d.y_nstride = _chk5(y, "y")
+        d.Nx = x.shape[0]
+        descs.append(d)
+        a = arr[i]
+        a.d = C.pointer(d)
+        a.x, a.w_packed, a.y = _p(x), _p(c["w"]), _p(y)
+        a.stats = _p(c.get("stats"))
+        a.bias = a.ep_scale = a.ep_shift = None
+        a.n_index = _p(c.get("n_index"), torch.int64)
+        a.relu = 0
+        a.accumulate = int(bool(c.get("accumulate", False)))
+    _lib.check(_L().coclr_conv3d_fwd_multi(arr, n, _stream()), "conv3d_fwd_multi",
+               [c["geom"] for c in calls])
+
+
 def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accumulate=False):
     """dw: the gradient tensor, or a list of up to four tensors that take consecutive blocks of
     output-channel rows (dw[i].shape[0] rows each, summing to geom.Cout)."""
@@ -364,6 +391,55 @@ def bn_finalize_apply(stats, C_, ntiles, count, gamma, beta, running_mean, runni
         _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(nbt, torch.int64), momentum, eps,
         _p(mean), _p(invstd), _p(scale), _p(shift), _p(y), _p(z), N, T * H * W, _chk5(y, "y"),
         _chk5(z, "z"), int(relu), _stream()), "bn_finalize_apply")
+
+
+def bn_finalize_apply_multi(units):
+    """bn_finalize_apply for several units in one call (one launch for runs of small units).
+    units: [dict(stats, C, ntiles, count, bn=(gamma, beta, running_mean, running_var, nbt, momentum, eps),
+    small=(mean, invstd, scale, shift), y, z, relu, c0=0, c_total=None)]."""
+    n = len(units)
+    arr = (BnFwdCall * n)()
+    for a, u in zip(arr, units):
+        C_, ntiles = u["C"], u["ntiles"]
+        c0 = u.get("c0", 0)
+        c_total = u.get("c_total") or C_
+        base = _p(u["stats"])
+        gamma, beta, rm, rv, nbt, momentum, eps = u["bn"]
+        mean, invstd, scale, shift = u["small"]
+        y, z = u["y"], u["z"]
+        N, _, T, H, W = y.shape
+        a.sum = base + 4 * c0 * ntiles
+        a.sumsq = base + 4 * (c_total + c0) * ntiles
+        a.gamma, a.beta, a.running_mean, a.running_var = _p(gamma), _p(beta), _p(rm), _p(rv)
+        a.num_batches_tracked = _p(nbt, torch.int64)
+        a.mean, a.invstd, a.scale, a.shift = _p(mean), _p(invstd), _p(scale), _p(shift)
+        a.y, a.z = _p(y), _p(z)
+        a.count = float(u["count"])
+        a.S = T * H * W
+        a.y_nstride, a.z_nstride = _chk5(y, "y"), _chk5(z, "z")
+        a.C, a.ntiles, a.N, a.relu = C_, ntiles, N, int(u["relu"])
+        a.momentum, a.eps = momentum, eps
+    _lib.check(_L().coclr_bn_finalize_apply_multi(arr, n, _stream()), "bn_finalize_apply_multi")
+
+
+def bn_act_backward_multi(units):
+    """bn_act_backward (no residual) for several units in one call.
+    units: [dict(dz, y, scale, shift, mean, invstd, sums, dy, dgamma, dbeta, relu, training)]."""
+    n = len(units)
+    arr = (BnBwdCall * n)()
+    for a, u in zip(arr, units):
+        y = u["y"]
+        N, C_, T, H, W = y.shape
+        if u["sums"].numel() < 2 * C_ * N:
+            raise ValueError("coclr_amd: bn_act_backward workspace too small")
+        a.dz, a.y, a.scale, a.shift = _p(u["dz"]), _p(y), _p(u["scale"]), _p(u["shift"])
+        a.mean, a.invstd = _p(u["mean"]), _p(u["invstd"])
+        a.sums_ws = _p(u["sums"], torch.float64)
+        a.dy, a.dgamma, a.dbeta = _p(u["dy"]), _p(u["dgamma"]), _p(u["dbeta"])
+        a.S = T * H * W
+        a.dz_nstride, a.y_nstride, a.dy_nstride = _chk5(u["dz"], "dz"), _chk5(y, "y"), _chk5(u["dy"], "dy")
+        a.N, a.C, a.relu, a.training = N, C_, int(u["relu"]), int(u["training"])
+    _lib.check(_L().coclr_bn_act_backward_multi(arr, n, _stream()), "bn_act_backward_multi")
 
 
 SMALL_CHANNEL = 32768      # N*S per channel up to which the one-launch BatchNorm forms are used

@@ -115,10 +115,9 @@ int coclr_conv3d_fwd(const coclr_conv_desc* d, const float* x, const float* w_pa
  * aten::conv3d calls of sibling branches: the (1,3,3) / (3,1,1) convolutions of branch1 and branch2 of an
  * inception block (backbone/s3dg.py:100-118), forward and data gradient -- on the 8x8x8 / 4x4x4 maps each
  * of them alone is a 10-40 us launch that leaves most of the chip idle.  Per-problem arguments are those
- * of coclr_conv3d_fwd.  The second problem of a pair is planned with the first one's tile where it can
- * take it, so its statistics layout is [2][Cout][ntiles] with the ntiles coclr_conv3d_multi_ntiles reports
- * for the same list of geometries (NOT necessarily coclr_conv3d_ntiles of the problem alone).
- * COCLR_PAIR=0 in the environment runs (and plans) every problem on its own. */
+ * of coclr_conv3d_fwd.  Every problem keeps the plan it would have alone (same tiles, same statistics
+ * layout: coclr_conv3d_ntiles), so outputs and statistics are bit-identical to separate calls.
+ * COCLR_PAIR=0 in the environment launches every problem on its own. */
 typedef struct coclr_conv_call {
   const coclr_conv_desc* d;
   const float* x;
@@ -132,7 +131,6 @@ typedef struct coclr_conv_call {
   int32_t relu, accumulate;
 } coclr_conv_call;
 int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void* stream);
-int coclr_conv3d_multi_ntiles(const coclr_conv_desc* const* descs, int n, int* ntiles);
 
 /* Split-K workspace (fp32 elements) for coclr_conv3d_wgrad. */
 int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* elems);
@@ -227,6 +225,32 @@ int coclr_maxpool3d_fwd(const coclr_pool_desc* d, const float* x, float* y, int3
 /* aten::max_pool3d_with_indices_backward, gather form (deterministic). */
 int coclr_maxpool3d_bwd(const coclr_pool_desc* d, const float* dy, const int32_t* indices, float* dx,
                         int64_t dy_nstride, int64_t dx_nstride, int accumulate, void* stream);
+
+/* Several BatchNorm units in one call: runs of up to four units that are small enough for the
+ * one-workgroup-per-channel form (N*S <= 32768, the last two stages of S3D) and share a vector width run
+ * as ONE launch whose grid is their channels back to back; everything else goes through the single-unit
+ * entry points, in order.  Fields as the arguments of coclr_bn_finalize_apply / coclr_bn_act_backward
+ * (no residual).  The three 1x1x1 heads of an inception block and the two separable branches side by
+ * side (backbone/s3dg.py:97-118): 10 us launches of 16-384 workgroups each. */
+typedef struct coclr_bn_fwd_call {
+  const float* sum; const float* sumsq; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float* mean; float* invstd; float* scale; float* shift;
+  const float* y; float* z;
+  double count;
+  int64_t S, y_nstride, z_nstride;
+  int32_t C, ntiles, N, relu;
+  float momentum, eps;
+} coclr_bn_fwd_call;
+typedef struct coclr_bn_bwd_call {
+  const float* dz; const float* y; const float* scale; const float* shift; const float* mean;
+  const float* invstd;
+  double* sums_ws; float* dy; float* dgamma; float* dbeta;
+  int64_t S, dz_nstride, y_nstride, dy_nstride;
+  int32_t N, C, relu, training;
+} coclr_bn_bwd_call;
+int coclr_bn_finalize_apply_multi(const coclr_bn_fwd_call* calls, int n, void* stream);
+int coclr_bn_act_backward_multi(const coclr_bn_bwd_call* calls, int n, void* stream);
 
 /* BatchNorm(+ReLU) backward of a unit whose only consumer is the max-pool described by `d` that
  * applied the unit's affine + ReLU while reading (coclr_maxpool3d_fwd with in_scale / in_shift): the

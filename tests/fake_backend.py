@@ -126,6 +126,28 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
     y.copy_(v)
 
 
+def conv_fwd_multi(calls):
+    """The pair / multi entry point: every problem on its own."""
+    for c in calls:
+        conv_fwd(c["geom"], c["x"], c["w"], c["y"], stats=c.get("stats"), n_index=c.get("n_index"),
+                 accumulate=c.get("accumulate", False))
+
+
+def bn_finalize_apply_multi(units):
+    for u in units:
+        gamma, beta, rm, rv, nbt, momentum, eps = u["bn"]
+        mean, invstd, scale, shift = u["small"]
+        bn_finalize_apply(u["stats"], u["C"], u["ntiles"], u["count"], gamma, beta, rm, rv, nbt, momentum,
+                          eps, mean, invstd, scale, shift, u["y"], u["z"], u["relu"], c0=u.get("c0", 0),
+                          c_total=u.get("c_total"))
+
+
+def bn_act_backward_multi(units):
+    for u in units:
+        bn_act_backward(u["dz"], u["y"], None, u["scale"], u["shift"], u["mean"], u["invstd"], u["sums"],
+                        u["dy"], None, u["dgamma"], u["dbeta"], u["relu"], u["training"])
+
+
 def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accumulate=False):
     w0 = torch.zeros(geom.Cout, geom.Cin, *geom.k, requires_grad=True)
     with torch.enable_grad():

@@ -1,0 +1,215 @@
+"""Multi-problem launches (ABI 15): coclr_conv3d_fwd_multi, coclr_bn_finalize_apply_multi,
+coclr_bn_act_backward_multi and the engine's lockstep emission of the two separable branches of an
+inception block (backbone/s3dg.py:100-118).  Every problem keeps the plan it has alone, so the bar is
+BIT-IDENTITY with the single launches: outputs, BatchNorm statistics, running buffers, gradients."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B = 32
+
+
+def _conv_case(run, cin, cout, k, p, idim, seed, dgrad=False, accumulate=False, stats=True):
+    from coclr_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    geom = ops.conv_geom(B, cin, cout, idim, k, (1, 1, 1), p)
+    w = torch.randn(cout, cin, *k, device="cuda", generator=g) * 0.05
+    if dgrad:
+        dg = geom.dgrad()
+        x = torch.randn(B, cout, *geom.odim, device="cuda", generator=g)
+        y0 = torch.randn(B, cin, *idim, device="cuda", generator=g)
+        return dict(geom=dg, x=x, w=run.pack(w, True, algo=dg.algo), y0=y0, accumulate=accumulate,
+                    stats=False, keep=w)
+    x = torch.randn(B, cin, *idim, device="cuda", generator=g)
+    y0 = torch.randn(B, cout, *geom.odim, device="cuda", generator=g)
+    return dict(geom=geom, x=x, w=run.pack(w, False, algo=geom.algo), y0=y0, accumulate=False, stats=stats,
+                keep=w)
+
+
+def _run_single(case):
+    from coclr_amd import ops
+    y = case["y0"].clone()
+    st = torch.full((2 * case["geom"].Cout * case["geom"].ntiles(),), 7.0, device="cuda") if case["stats"] else None
+    ops.conv_fwd(case["geom"], case["x"], case["w"], y, stats=st, accumulate=case["accumulate"])
+    return y, st
+
+
+PAIRS = [
+    # (1,3,3) direct, the wide branch on 64x128 tiles and the narrow one on 64x64: mixed-variant launch
+    ("4b conv1", (96, 208, (1, 3, 3), (0, 1, 1), (8, 8, 8)), (16, 48, (1, 3, 3), (0, 1, 1), (8, 8, 8))),
+    # same variant
+    ("4f conv1", (160, 320, (1, 3, 3), (0, 1, 1), (8, 8, 8)), (32, 128, (1, 3, 3), (0, 1, 1), (8, 8, 8))),
+    ("5c conv1", (192, 384, (1, 3, 3), (0, 1, 1), (4, 4, 4)), (48, 128, (1, 3, 3), (0, 1, 1), (4, 4, 4))),
+    # temporal Winograd
+    ("4b conv2", (208, 208, (3, 1, 1), (1, 0, 0), (8, 8, 8)), (48, 48, (3, 1, 1), (1, 0, 0), (8, 8, 8))),
+    ("5c conv2", (384, 384, (3, 1, 1), (1, 0, 0), (4, 4, 4)), (128, 128, (3, 1, 1), (1, 0, 0), (4, 4, 4))),
+    # 16x16x16 maps: spatial Winograd (no pair kernel: two launches inside the call) and temporal pairs
+    ("3b conv1", (96, 128, (1, 3, 3), (0, 1, 1), (16, 16, 16)), (16, 32, (1, 3, 3), (0, 1, 1), (16, 16, 16))),
+    ("3b conv2", (128, 128, (3, 1, 1), (1, 0, 0), (16, 16, 16)), (32, 32, (3, 1, 1), (1, 0, 0), (16, 16, 16))),
+    # not the same stencil at all: falls apart into two launches, results unchanged
+    ("mismatch", (96, 208, (1, 3, 3), (0, 1, 1), (8, 8, 8)), (480, 64, (1, 1, 1), (0, 0, 0), (8, 8, 8))),
+]
+
+
+@pytest.mark.parametrize("name,a,b", PAIRS, ids=[p[0] for p in PAIRS])
+@pytest.mark.parametrize("mode", ["forward", "dgrad", "dgrad_accumulate"])
+def test_conv_pairs_are_bit_identical_to_single_launches(name, a, b, mode):
+    from coclr_amd import engine, ops
+    run = engine.Run(torch.device("cuda"), save=False)
+    dgrad = mode != "forward"
+    cases = [_conv_case(run, *spec, seed=11 + i, dgrad=dgrad, accumulate=mode == "dgrad_accumulate")
+             for i, spec in enumerate((a, b))]
+    singles = [_run_single(c) for c in cases]
+    ys = [c["y0"].clone() for c in cases]
+    sts = [torch.full((2 * c["geom"].Cout * c["geom"].ntiles(),), 7.0, device="cuda") if c["stats"] else None
+           for c in cases]
+    ops.conv_fwd_multi([dict(geom=c["geom"], x=c["x"], w=c["w"], y=y, stats=st, accumulate=c["accumulate"])
+                        for c, y, st in zip(cases, ys, sts)])
+    torch.cuda.synchronize()
+    for (y1, s1), y2, s2 in zip(singles, ys, sts):
+        assert torch.equal(y1, y2), "%s %s: outputs differ" % (name, mode)
+        if s1 is not None:
+            assert torch.equal(s1, s2), "%s %s: statistics differ" % (name, mode)
+
+
+def _bn_units(seed, shapes, slices=False):
+    """BatchNorm units over freshly drawn tensors; `slices`: the units' y are channel ranges of one wider
+    tensor and share one statistics buffer (the fused heads of an inception block)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    units = []
+    if slices:
+        N, dims = shapes[0][0], shapes[0][2]
+        ctot = sum(s[1] for s in shapes)
+        ywide = torch.randn(N, ctot, *dims, device="cuda", generator=g)
+        ntiles = 16
+        stats = torch.rand(2 * ctot * ntiles, device="cuda", generator=g)
+    c0 = 0
+    for (N, C_, dims) in shapes:
+        y = ywide[:, c0:c0 + C_] if slices else torch.randn(N, C_, *dims, device="cuda", generator=g)
+        nt = ntiles if slices else 8
+        st = stats if slices else torch.rand(2 * C_ * nt, device="cuda", generator=g)
+        # partial sums consistent with y would be needed for meaningful statistics; any finite numbers do
+        # for an identity check of the arithmetic (sumsq kept large enough for a positive variance)
+        if not slices:
+            st[C_ * nt:] += 4.0
+        units.append(dict(N=N, C=C_, dims=dims, y=y, stats=st, ntiles=nt, c0=c0 if slices else 0,
+                          c_total=ctot if slices else None,
+                          gamma=torch.rand(C_, device="cuda", generator=g) + 0.5,
+                          beta=torch.randn(C_, device="cuda", generator=g)))
+        c0 += C_
+    if slices:
+        stats[ctot * ntiles:] += 4.0
+    return units
+
+
+def _bn_forward(units, multi):
+    from coclr_amd import ops
+    outs, calls = [], []
+    for u in units:
+        C_ = u["C"]
+        small = torch.zeros(4, C_, device="cuda")
+        rm, rv = torch.zeros(C_, device="cuda"), torch.ones(C_, device="cuda")
+        nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        z = torch.empty(u["N"], C_, *u["dims"], device="cuda")
+        count = u["N"] * u["dims"][0] * u["dims"][1] * u["dims"][2]
+        outs.append((z, small, rm, rv, nbt))
+        calls.append(dict(stats=u["stats"], C=C_, ntiles=u["ntiles"], count=count,
+                          bn=(u["gamma"], u["beta"], rm, rv, nbt, 0.1, 1e-5),
+                          small=(small[0], small[1], small[2], small[3]), y=u["y"], z=z, relu=True,
+                          c0=u["c0"], c_total=u["c_total"]))
+    if multi:
+        ops.bn_finalize_apply_multi(calls)
+    else:
+        for c in calls:
+            gamma, beta, rm, rv, nbt, mom, eps = c["bn"]
+            ops.bn_finalize_apply(c["stats"], c["C"], c["ntiles"], c["count"], gamma, beta, rm, rv, nbt, mom,
+                                  eps, *c["small"], c["y"], c["z"], True, c0=c["c0"], c_total=c["c_total"])
+    torch.cuda.synchronize()
+    return outs
+
+
+BN_CASES = [
+    ("heads 4b", [(B, 192, (8, 8, 8)), (B, 96, (8, 8, 8)), (B, 16, (8, 8, 8))], True),
+    ("pair 4b", [(B, 208, (8, 8, 8)), (B, 48, (8, 8, 8))], False),
+    ("pair 5c", [(B, 384, (4, 4, 4)), (B, 128, (4, 4, 4))], False),
+    ("five units", [(B, 24, (4, 4, 4))] * 5, False),
+    # 16x16x16 maps are beyond the one-workgroup-per-channel form: single-unit launches inside the call
+    ("large + small", [(B, 32, (16, 16, 16)), (B, 48, (8, 8, 8)), (B, 64, (8, 8, 8))], False),
+    ("odd plane (scalar path)", [(4, 8, (1, 3, 3)), (4, 5, (1, 3, 3))], False),
+]
+
+
+@pytest.mark.parametrize("name,shapes,slices", BN_CASES, ids=[c[0] for c in BN_CASES])
+def test_batchnorm_multi_is_bit_identical(name, shapes, slices):
+    from coclr_amd import ops
+    units = _bn_units(5, shapes, slices)
+    one = _bn_forward(units, multi=False)
+    many = _bn_forward(units, multi=True)
+    for a, b in zip(one, many):
+        for t1, t2 in zip(a, b):
+            assert torch.equal(t1, t2), name
+    # backward: dy, dgamma, dbeta
+    g = torch.Generator(device="cuda").manual_seed(9)
+    res = []
+    for multi in (False, True):
+        calls, outs = [], []
+        for u, (z, small, rm, rv, nbt) in zip(units, one):
+            dz = torch.randn(z.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+            dy = torch.empty_like(z)
+            dgb = torch.empty(2, u["C"], device="cuda")
+            sums = torch.empty(ops.bn_backward_workspace(u["N"], u["C"]), dtype=torch.float64, device="cuda")
+            calls.append(dict(dz=dz, y=u["y"], scale=small[2], shift=small[3], mean=small[0], invstd=small[1],
+                              sums=sums, dy=dy, dgamma=dgb[0], dbeta=dgb[1], relu=True, training=True))
+            outs.append((dy, dgb))
+        if multi:
+            ops.bn_act_backward_multi(calls)
+        else:
+            for c in calls:
+                ops.bn_act_backward(c["dz"], c["y"], None, c["scale"], c["shift"], c["mean"], c["invstd"],
+                                    c["sums"], c["dy"], None, c["dgamma"], c["dbeta"], True, True)
+        torch.cuda.synchronize()
+        res.append(outs)
+    for (dy1, dgb1), (dy2, dgb2) in zip(*res):
+        assert torch.equal(dy1, dy2) and torch.equal(dgb1, dgb2), name
+
+
+@pytest.mark.parametrize("block,dims", [("Mixed_4b", (8, 8, 8)), ("Mixed_4f", (8, 8, 8)), ("Mixed_5c", (4, 4, 4)),
+                                        ("Mixed_3b", (16, 16, 16))])
+def test_paired_inception_block_matches_unpaired(block, dims, monkeypatch):
+    """One inception block, forward and backward, with the branch tails emitted in lockstep (default) and
+    one unit after the other: output, input gradient, every parameter gradient and every BatchNorm buffer
+    bit-identical; so is the library-level switch COCLR_PAIR=0."""
+    from coclr_amd import engine
+    from coclr_amd.backbone import s3dg
+    from test_gpu_engine import randomise
+    cin, widths = s3dg._INCEPTION[block]
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, cin, *dims, generator=g).relu()
+    dout = None
+    results = []
+    for pair_units, lib_pair in ((True, "1"), (False, "1"), (True, "0")):
+        monkeypatch.setattr(engine, "PAIR_UNITS", pair_units)
+        monkeypatch.setenv("COCLR_PAIR", lib_pair)
+        torch.manual_seed(0)
+        m = s3dg.SepInception(cin, list(widths))
+        randomise(m, 7)
+        m = m.cuda().train()
+        xg = x.cuda().requires_grad_(True)
+        out = m(xg)
+        if dout is None:
+            dout = torch.randn(out.shape, generator=torch.Generator().manual_seed(4)).cuda()
+        out.backward(dout)
+        torch.cuda.synchronize()
+        results.append((out.detach().clone(), xg.grad.clone(),
+                        {k: p.grad.clone() for k, p in m.named_parameters()},
+                        {k: v.clone() for k, v in m.named_buffers()}))
+    ref = results[0]
+    for other in results[1:]:
+        assert torch.equal(ref[0], other[0]) and torch.equal(ref[1], other[1])
+        for k in ref[2]:
+            assert torch.equal(ref[2][k], other[2][k]), k
+        for k in ref[3]:
+            assert torch.equal(ref[3][k], other[3][k]), k

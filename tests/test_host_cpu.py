@@ -579,3 +579,33 @@ def test_pull_shuffle_falls_back_to_routed_on_every_rank():
         p.join(60)
     for rank, msg in results:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def test_lockstep_emission_of_the_branch_tails_matches_sequential(fake, monkeypatch):
+    """engine.drive_pair (the two separable branches of an inception block as coroutines in lockstep,
+    their backward closures paired on the tape) against one unit after the other: same launches in a
+    different order, identical results -- forward, every gradient, BatchNorm buffers (host logic; the
+    fused kernels themselves are held to bit-identity on the GPU, tests/test_gpu_multi.py)."""
+    from coclr_amd import engine
+    from coclr_amd.backbone import s3dg
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 480, 4, 8, 8, generator=g).relu()
+    dout = torch.randn(2, 512, 4, 8, 8, generator=g)
+    results = []
+    for pair in (True, False):
+        monkeypatch.setattr(engine, "PAIR_UNITS", pair)
+        torch.manual_seed(0)
+        m = s3dg.SepInception(480, [192, 96, 208, 16, 48, 64]).train()
+        xg = x.clone().requires_grad_(True)
+        out = m(xg)
+        out.backward(dout)
+        results.append((out.detach().clone(), xg.grad.clone(),
+                        {k: p.grad.clone() for k, p in m.named_parameters()},
+                        {k: v.clone() for k, v in m.named_buffers()}))
+    a, b = results
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(p is not None for p in a[2].values()) and len(a[2]) == 24
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
