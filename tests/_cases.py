@@ -146,6 +146,11 @@ def recorded_truth(rec):
     return t
 
 
+# upper end of the reference arithmetic's own raw fp32-vs-float64 gradient error on the conditioned fixture
+# under one-ulp input perturbations (profiles/r04_grad_error_budget.txt, section 4)
+RAW_SPREAD = 2.5e-2
+
+
 def compare_step(rec, kind, out, tgt, loss, named_grads, tol=REL_TOL, truth=None,
                  grad_factor=4.0, grad_floor=1e-3, report=None, strict=False):
     """logits / target / loss of one step vs the golden record (the north-star 1e-3),
@@ -203,20 +208,23 @@ def compare_step(rec, kind, out, tgt, loss, named_grads, tol=REL_TOL, truth=None
     assert med_got <= grad_factor * med_ref + grad_floor, \
         "median grad err vs fp64 truth %.3e, reference's own %.3e" % (med_got, med_ref)
     if strict:
-        # De-saturated fixture with float64 truth from the reference itself: EVERY sampled tensor, in
-        # the L2 norm, within grad_factor x the reference's own fp32-vs-fp64 error.  That error is
-        # 1.6e-2 on every tensor below stage 5 (it enters in the stage-5 BatchNorms: ~100 values per
-        # channel at random weights; upstream tensors inherit it linearly) and happens to be 4e-4 on
-        # Mixed_5c.branch1.1.conv2.weight, where the product already carries its stage-5 noise
-        # (measured on MI355X: 2.7e-2 on every backbone tensor, Winograd on or off, 1.5-2.6e-2 on that
-        # one) -- so a tensor is held to the larger of its own and the median reference error.
+        # De-saturated fixture with float64 truth from the reference itself: EVERY sampled tensor, in the
+        # L2 norm.  What this RAW comparison can and cannot show (round 4, tools/grad_error_budget.py,
+        # profiles/r04_grad_error_budget.txt): the reference's own fp32-vs-float64 error here (1.5e-2) is
+        # made of ~1e2 ReLU / max-pool decisions taken differently at near ties -- with the decisions
+        # conditioned away 1.4e-4 is left -- and the SAME reference arithmetic on inputs perturbed by one
+        # ulp lands anywhere in 1.5e-2 .. 2.5e-2 (six seeds).  The product's raw error (2.7e-2 in round 3)
+        # is a draw from that distribution, so a tensor is held to grad_factor x the larger of the
+        # reference's own error on it, the median, and the upper end of that spread.  The tight statement
+        # -- every tensor within 2x the reference arithmetic's round-off once the decisions are the same
+        # -- is tests/test_gpu_gradients.py.
         l2 = {}
         for k, ref in rec["grads"].items():
             t = truth[k] if truth.get("__sampled__") else sample(truth[k])
             l2[k] = (l2_err(sample(named_grads[k]), t), l2_err(ref, t))
         refs_sorted = sorted(v[1] for v in l2.values())
         med = refs_sorted[len(refs_sorted) // 2]
-        bad = [(k, g, r) for k, (g, r) in l2.items() if g > grad_factor * max(r, med)]
+        bad = [(k, g, r) for k, (g, r) in l2.items() if g > grad_factor * max(r, med, RAW_SPREAD)]
         assert not bad, "gradient tensors beyond %.0fx the reference's own fp32 error (L2): %s" % (
             grad_factor, bad)
         return

@@ -149,13 +149,11 @@ def test_config4_coclr_two_stream_step_matches_oracle():
 
 
 def test_config5_r50_k16384_step_matches_oracle():
-    """ResNet2d3d-50 at the benchmarked clip size.  B = 16 here (the oracle's forward + backward of
-    r50 at B=32 is over a minute of host time; every r50 conv geometry is exercised at B=32 by
-    test_gpu_fullsize.py's adjoint identities)."""
+    """ResNet2d3d-50 at the benchmarked clip size and batch (B = 32 per GPU, BASELINE config 5)."""
     import model.pretrain as product
     from oracle import coclr_oracle as orc
     from _cases import check_close
-    K, Bs = 16384, (16 if B == 32 else B)
+    K, Bs = 16384, B
     torch.manual_seed(0)
     model = product.InfoNCE('r50', 128, K, 0.999, 0.07)
     ref_sd = orc.training_state(model.state_dict())

@@ -70,8 +70,9 @@ def _replay(name, with_pg=False):
         after = model.state_dict()
         if step == 0:
             report = []
-            compare_step(rec, kind, out, tgt, loss, grads, truth=truth, report=report,
-                         strict="grads64" in rec)
+            strict = "grads64" in rec
+            compare_step(rec, kind, out, tgt, loss, grads, truth=truth, report=report, strict=strict,
+                         grad_factor=2.0 if strict else 4.0)
             for k, e_got, e_ref in report:
                 print("%s grad %-50s err vs fp64 %.2e (reference fp32: %.2e)" % (name, k, e_got,
                                                                                e_ref))
@@ -112,7 +113,8 @@ def test_small_cases_match_reference(name):
 def test_conditioned_case_every_gradient_tensor():
     """De-saturated, He-initialised fixture (loss ~ 4.9 instead of ~5e-3) with float64 gradients
     recorded from the REFERENCE model itself run in double: every one of the 26 sampled tensors --
-    stem to head -- is held, in the L2 norm, to 4x the reference's own fp32-vs-fp64 error."""
+    stem to head -- is held, in the L2 norm, to 2x the reference arithmetic's own raw fp32-vs-float64
+    error (see _cases.compare_step, strict; the decision-conditioned form is test_gpu_gradients.py)."""
     _replay("infonce_s3d_conditioned")
 
 
