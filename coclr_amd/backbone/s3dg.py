@@ -64,6 +64,9 @@ class BasicConv3d(_Emitter):
     def _emit(self, run, x, out=None, n_index=None):
         return engine.conv_bn_act(run, x, self.conv, self.bn, relu=True, out=out, n_index=n_index)
 
+    def _emit_gen(self, run, x, out=None):
+        return (yield from engine.conv_bn_act_gen(run, x, self.conv, self.bn, relu=True, out=out))
+
 
 class STConv3d(_Emitter):
     """Separable conv: (1,k,k) spatial then (k,1,1) temporal, each with BN+ReLU.
@@ -173,18 +176,24 @@ class SepInception(_Emitter):
             c0 += width
         # the three 1x1x1 heads read the same x: one convolution over concatenated channels
         b0, b1a, b2a = self.branch0[0], self.branch1[0], self.branch2[0]
-        heads = engine.pointwise_group(run, x, [(b0.conv, b0.bn, None if self.gating else dst[0]),
-                                                (b1a.conv, b1a.bn, None), (b2a.conv, b2a.bn, None)])
+        head_units = [(b0.conv, b0.bn, None if self.gating else dst[0]), (b1a.conv, b1a.bn, None),
+                      (b2a.conv, b2a.bn, None)]
         tails = (None, self.branch1[1], self.branch2[1])
-        if self.gating:
-            getattr(self, "gating_b0")._emit(run, heads[0], out=dst[0])
         if engine.PAIR_UNITS and not self.gating and not run.lanes_on:
-            # the separable tails of branch 1 and branch 2 share every stencil shape: emitted in lockstep,
-            # their convolutions / BatchNorm passes / data gradients run as one launch each
+            # Sibling units in lockstep, one launch per step of the pair (engine.drive_pair):
+            #   * the fused heads and the pool branch's 1x1x1 convolution (both pointwise, both on the block's
+            #     map: x and the pooled x), then their four BatchNorm units;
+            #   * the separable tails of branch 1 and branch 2 (same stencils): convolutions, BatchNorm
+            #     passes and, in backward, BatchNorm backward passes and data gradients.
+            pooled = self.branch3[0]._emit(run, x)
+            heads, _ = engine.drive_pair(run, engine.pointwise_group_gen(run, x, head_units),
+                                         self.branch3[1]._emit_gen(run, pooled, out=dst[3]))
             engine.drive_pair(run, tails[1]._emit_gen(run, heads[1], out=dst[1]),
                               tails[2]._emit_gen(run, heads[2], out=dst[2]))
-            self.branch3._emit(run, x, out=dst[3])
             return engine.Val(block)
+        heads = engine.pointwise_group(run, x, head_units)
+        if self.gating:
+            getattr(self, "gating_b0")._emit(run, heads[0], out=dst[0])
         # the separable tails of branch 1 / 2 and the pool branch are independent of each other:
         # one lane (HIP stream) each, joined before the block output is consumed
         for i in (1, 2, 3):

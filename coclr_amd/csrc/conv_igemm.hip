@@ -1794,8 +1794,9 @@ int launch_variant(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot 
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
   const long blocks = (long)a.mtiles * a.ntiles;
-  // pair kernels exist for the stencil the two separable branches of an inception block share
-  constexpr bool PAIRABLE = KT == 1 && KH == 3 && KW == 3;
+  // pair kernels exist for the stencils sibling units of an inception block share: (1,3,3) of the two
+  // separable branches, 16-byte-staged (1,1,1) of the fused heads and the pool branch
+  constexpr bool PAIRABLE = KT == 1 && ((KH == 3 && KW == 3) || (KH == 1 && KW == 1 && XV4));
   if (slot && PAIRABLE) {
     slot->args = a; slot->blocks = blocks; slot->lds = lds; slot->pending = true;
     slot->single = &variant_single<KT, KH, KW, CC, BM, BN, PCH, XV4, XG>;
@@ -2100,16 +2101,16 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
                   (p.Wi % 4) == 0 && (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 &&
                   ((uintptr_t)x % 16) == 0 && granule_count(p) <= 192;
   switch (variant) {
-    case 0:  return xv4 ? launch_variant<1, 1, 1, 32, 128, 128, 2, true>(a, p, stream)
+    case 0:  return xv4 ? launch_variant<1, 1, 1, 32, 128, 128, 2, true>(a, p, stream, slot)
                         : launch_variant<1, 1, 1, 32, 128, 128, 2>(a, p, stream);
     // 16-byte-staged kernels run with HALF the channel chunk of their 4-byte forms: the chunk is what
     // sizes the LDS stages, and two or three workgroups per CU became five or six.  Measured at B=32
     // (same box, alternating): Conv_2b 0.082 -> 0.070 ms forward / 0.070 -> 0.059 data gradient, the
     // fused heads of Mixed_3c 0.223 -> 0.20 / 0.19 -> 0.195, of Mixed_4b 0.058 -> 0.054 / 0.060 ->
     // 0.051, Conv_1a.conv2 1.36 -> 1.31; the (1,3,3) small-map kernel did not move and keeps 8.
-    case 1:  return xv4 ? launch_variant<1, 1, 1, 16, 64, 128, 2, true>(a, p, stream)
+    case 1:  return xv4 ? launch_variant<1, 1, 1, 16, 64, 128, 2, true>(a, p, stream, slot)
                         : launch_variant<1, 1, 1, 32, 64, 128, 2>(a, p, stream);
-    case 2:  return xv4 ? launch_variant<1, 1, 1, 16, 64, 64, 1, true>(a, p, stream)
+    case 2:  return xv4 ? launch_variant<1, 1, 1, 16, 64, 64, 1, true>(a, p, stream, slot)
                         : launch_variant<1, 1, 1, 32, 64, 64, 1>(a, p, stream);
     case 3:  return launch_variant<1, 1, 1, 16, 64, 64, 4>(a, p, stream);
     case 10: return xg ? launch_variant<1, 3, 3, 4, 128, 128, 3, false, true>(a, p, stream, slot)

@@ -558,16 +558,24 @@ def _exec(req):
         ops.conv_fwd(c["geom"], c["x"], c["w"], c["y"], stats=stats, n_index=c.get("n_index"),
                      accumulate=c.get("accumulate", False))
         return stats, nt
-    if kind == "bn_fwd":
-        gamma, beta, rm, rv, nbt, momentum, eps = c["bn"]
-        mean, invstd, scale, shift = c["small"]
-        ops.bn_finalize_apply(c["stats"], c["C"], c["ntiles"], c["count"], gamma, beta, rm, rv, nbt, momentum,
-                              eps, mean, invstd, scale, shift, c["y"], c["z"], c["relu"], c0=c.get("c0", 0),
-                              c_total=c.get("c_total"))
+    if kind == "bn_fwd":           # c: list of units
+        if len(c) > 1:
+            ops.bn_finalize_apply_multi(c)
+            return None
+        u = c[0]
+        gamma, beta, rm, rv, nbt, momentum, eps = u["bn"]
+        mean, invstd, scale, shift = u["small"]
+        ops.bn_finalize_apply(u["stats"], u["C"], u["ntiles"], u["count"], gamma, beta, rm, rv, nbt, momentum,
+                              eps, mean, invstd, scale, shift, u["y"], u["z"], u["relu"], c0=u.get("c0", 0),
+                              c_total=u.get("c_total"))
         return None
-    if kind == "bn_bwd":
-        ops.bn_act_backward(c["dz"], c["y"], None, c["scale"], c["shift"], c["mean"], c["invstd"], c["sums"],
-                            c["dy"], None, c["dgamma"], c["dbeta"], c["relu"], c["training"])
+    if kind == "bn_bwd":           # c: list of units
+        if len(c) > 1:
+            ops.bn_act_backward_multi(c)
+            return None
+        u = c[0]
+        ops.bn_act_backward(u["dz"], u["y"], None, u["scale"], u["shift"], u["mean"], u["invstd"], u["sums"],
+                            u["dy"], None, u["dgamma"], u["dbeta"], u["relu"], u["training"])
         return None
     raise RuntimeError("coclr_amd: unknown launch request %r" % (kind,))
 
@@ -587,10 +595,10 @@ def _exec_pair(ra, rb):
         ops.conv_fwd_multi([ca, cb])
         return res[0], res[1]
     if kind == "bn_fwd":
-        ops.bn_finalize_apply_multi([ca, cb])
+        ops.bn_finalize_apply_multi(list(ca) + list(cb))
         return None, None
     if kind == "bn_bwd":
-        ops.bn_act_backward_multi([ca, cb])
+        ops.bn_act_backward_multi(list(ca) + list(cb))
         return None, None
     return _exec(ra), _exec(rb)
 
@@ -736,10 +744,10 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
                 raise NotImplementedError("coclr_amd: cumulative-average BatchNorm momentum")
             if residual is None and not lazy:
                 # statistics + apply in one call (a single launch for the small late-stage layers)
-                yield ("bn_fwd", dict(stats=stats, C=Cout, ntiles=ntiles, count=count,
-                                      bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                          bn.num_batches_tracked, float(bn.momentum), float(bn.eps)),
-                                      small=(mean, invstd, scale, shift), y=y, z=zv, relu=relu))
+                yield ("bn_fwd", [dict(stats=stats, C=Cout, ntiles=ntiles, count=count,
+                                       bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                           bn.num_batches_tracked, float(bn.momentum), float(bn.eps)),
+                                       small=(mean, invstd, scale, shift), y=y, z=zv, relu=relu)])
             else:
                 ops.bn_finalize(stats, Cout, ntiles, count, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked,
@@ -781,9 +789,9 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
                 ops.bn_act_backward_pooled(pooled[0], pooled[1], pooled[2], y, scale, shift, mean,
                                            invstd, sums, dy, dgb[0], dgb[1], relu, training)
             elif residual is None:
-                yield ("bn_bwd", dict(dz=run.grad_of(out), y=y, scale=scale, shift=shift, mean=mean,
-                                      invstd=invstd, sums=sums, dy=dy, dgamma=dgb[0], dbeta=dgb[1], relu=relu,
-                                      training=training))
+                yield ("bn_bwd", [dict(dz=run.grad_of(out), y=y, scale=scale, shift=shift, mean=mean,
+                                       invstd=invstd, sums=sums, dy=dy, dgamma=dgb[0], dbeta=dgb[1], relu=relu,
+                                       training=training)])
             else:
                 dz = run.grad_of(out)
                 dres = None
@@ -831,6 +839,11 @@ FUSE_POINTWISE = True     # debugging switch: False runs the units of a group on
 
 
 def pointwise_group(run, x, units):
+    """pointwise_group_gen, executed at once."""
+    return _drive(pointwise_group_gen(run, x, units))
+
+
+def pointwise_group_gen(run, x, units):
     """Several 1x1x1 conv+BN+ReLU units that read the SAME input -- the heads of an inception
     block, branch0 / branch1[0] / branch2[0] (backbone/s3dg.py:97-104,119-123) -- executed as
     one convolution over their concatenated output channels: one pass over x instead of
@@ -842,7 +855,10 @@ def pointwise_group(run, x, units):
     (BN+ReLU then fold into each conv's epilogue)."""
     training = all(bn.training or bn.running_mean is None for _, bn, _ in units)
     if not (training or run.save) or len(units) == 1 or not FUSE_POINTWISE:
-        return [conv_bn_act(run, x, conv, bn, relu=True, out=out) for conv, bn, out in units]
+        res = []
+        for conv, bn, out in units:
+            res.append((yield from conv_bn_act_gen(run, x, conv, bn, relu=True, out=out)))
+        return res
     for conv, bn, _ in units:
         if tuple(conv.weight.shape[2:]) != (1, 1, 1) or _triple(conv.stride) != (1, 1, 1) or \
                 _triple(conv.padding) != (0, 0, 0) or conv.bias is not None or \
@@ -856,8 +872,8 @@ def pointwise_group(run, x, units):
     xv = x.view()
     y = run.empty(N, Ccat, *idim)
     ntiles = geom.ntiles()
-    stats = run.empty(2 * Ccat * ntiles) if training else None
-    ops.conv_fwd(geom, xv, run.pack_concat(weights, False), y, stats=stats)
+    stats, _ = yield ("conv", dict(geom=geom, x=xv, w=run.pack_concat(weights, False), y=y,
+                                   want_stats=training))
     count = N * idim[0] * idim[1] * idim[2]
     outs, saved = [], []
     c0 = 0
@@ -886,7 +902,7 @@ def pointwise_group(run, x, units):
         c0 += C_
     if fwd_units:
         # the heads' BatchNorm units in one call (one launch on the 8x8x8 / 4x4x4 maps)
-        ops.bn_finalize_apply_multi(fwd_units)
+        yield ("bn_fwd", fwd_units)
     if run.save and DECISION_PROBE is not None:
         for (conv, bn, _), (c0_, C_, mean, invstd, scale, shift) in zip(units, saved):
             _probe_relu(bn, y[:, c0_:c0_ + C_], scale, shift)
@@ -904,7 +920,7 @@ def pointwise_group(run, x, units):
                                       mean=mean, invstd=invstd, sums=sums, dy=dy[:, c0:c0 + C_],
                                       dgamma=dgb[0], dbeta=dgb[1], relu=True, training=training))
                 dgbs.append(dgb)
-            ops.bn_act_backward_multi(bwd_units)
+            yield ("bn_bwd", bwd_units)
             for (conv, bn, _), dgb in zip(units, dgbs):
                 if bn.weight.requires_grad:
                     run.add_param_grad(bn.weight, dgb[0])
@@ -926,7 +942,8 @@ def pointwise_group(run, x, units):
                         run.add_param_grad(w, dw)
             if x_needs:
                 dx, acc = run.grad_target(x)
-                ops.conv_fwd(geom.dgrad(), dy, run.pack_concat(weights, True), dx, accumulate=acc)
+                yield ("conv", dict(geom=geom.dgrad(), x=dy, w=run.pack_concat(weights, True), y=dx,
+                                    accumulate=acc))
 
         run.record(backward)
     return outs

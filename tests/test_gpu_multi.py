@@ -49,6 +49,10 @@ PAIRS = [
     # 16x16x16 maps: spatial Winograd (no pair kernel: two launches inside the call) and temporal pairs
     ("3b conv1", (96, 128, (1, 3, 3), (0, 1, 1), (16, 16, 16)), (16, 32, (1, 3, 3), (0, 1, 1), (16, 16, 16))),
     ("3b conv2", (128, 128, (3, 1, 1), (1, 0, 0), (16, 16, 16)), (32, 32, (3, 1, 1), (1, 0, 0), (16, 16, 16))),
+    # pointwise: the fused heads of a block beside the pool branch's convolution
+    ("4b heads+b3", (480, 304, (1, 1, 1), (0, 0, 0), (8, 8, 8)), (480, 64, (1, 1, 1), (0, 0, 0), (8, 8, 8))),
+    ("5c heads+b3", (832, 624, (1, 1, 1), (0, 0, 0), (4, 4, 4)), (832, 128, (1, 1, 1), (0, 0, 0), (4, 4, 4))),
+    ("3c heads+b3", (256, 288, (1, 1, 1), (0, 0, 0), (16, 16, 16)), (256, 64, (1, 1, 1), (0, 0, 0), (16, 16, 16))),
     # not the same stencil at all: falls apart into two launches, results unchanged
     ("mismatch", (96, 208, (1, 3, 3), (0, 1, 1), (8, 8, 8)), (480, 64, (1, 1, 1), (0, 0, 0), (8, 8, 8))),
 ]
