@@ -274,12 +274,24 @@ __device__ __forceinline__ int w2_fdiv(int e, float inv) { return (int)(((float)
 // positions; the epilogue maps back dg0 = dU0 + (dU1+dU2)/2, dg1 = (dU1-dU2)/2,
 // dg2 = (dU1+dU2)/2 + dU3.  Seen from the code below it is a (4,1,1) stencil with temporal stride 2
 // over pair positions whose operands are sums / differences of two LDS reads.
-template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false, int NL = 4>
+//
+// WHW ((1,3,3) stride-1 pad-1 stencils on even maps, the layers whose forward runs through F(2x2,3x3)):
+// the gradient is accumulated in the Winograd domain.  Per 2x2 block of outputs
+//     dM = A dY A^T (4x4 from the 2x2 block of dY)      V = B^T d B (4x4 from the 4x4 input patch)
+//     dU[xi] (co, ci) += dM[xi] (co, block) * V[xi] (ci, block)          xi = 4i + j
+// and the epilogue maps back dg = G^T dU G: SIXTEEN MFMAs per two blocks (8 positions) instead of the
+// 36 of the direct form.  A workgroup owns 32 co x 64 ci; matrix wave (xh, wn) owns rows i = 2xh, 2xh+1 of
+// xi for ci block wn: 8 accumulator sets (128 registers, so a loader wave still shares its SIMD).  G^T . G
+// is linear in dU, so each xi-half writes its own partial 3x3 as an extra split slice (2 S slices in all)
+// and wgrad_reduce_kernel folds them.  Signs: A = [[1,0],[1,1],[1,-1],[0,-1]]; the kernel feeds +b where
+// A says -b (row 3 / column 3 of dM) and the epilogue applies s(i) s(j), s = (+,+,+,-).
+template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false, int NL = 4, bool WHW = false>
 __global__ void __launch_bounds__(256 + 64 * NL)
 conv_wgrad2_kernel(const Wgrad2Args a) {
   constexpr int TAPS = KT * KH * KW;
   constexpr int BP = WINO ? 32 : 64;     // positions (WINO: frame pairs) per box
-  constexpr int BMt = 64 * MB, BCt = 64 * NB;
+  constexpr int BMt = WHW ? 32 : 64 * MB, BCt = 64 * NB;
+  static_assert(!WHW || (KT == 1 && KH == 3 && KW == 3 && MB == 1 && NB == 1 && !WINO), "F(2x2,3x3) form");
   constexpr int LDY = 64 + 1;            // WINO: [32 first frames | 32 second frames] per row
   constexpr int STEPS = BP / 2;
   static_assert(!WINO || (KT == 4 && KH == 1 && KW == 1), "Winograd form is the (4,1,1)/2 view");
@@ -392,6 +404,104 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
   // ================================ matrix waves ================================
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
+  if constexpr (WHW) {
+    const int xh = wm;                                   // rows i = 2 xh, 2 xh + 1 of xi = 4 i + j
+    const int TWb = 1 << lW;                             // box width in positions
+    const int abase = l31 * LDY + 2 * half;              // lanes 32-63: the block two columns to the right
+    const int jbase = BMt * LDY + (wn * 32 + l31) * planeP + 2 * half;
+    f32x16 accw[2][4];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[ii][j][e] = 0.f;
+    // block pair s: blocks 2s, 2s+1 are neighbours along w (box width >= 4); wave-uniform decode
+    auto offs = [&](int s, int& p, int& wo) {
+      const int b0 = 2 * s;
+      const int bw = b0 & ((1 << (lW - 1)) - 1);
+      int r = b0 >> (lW - 1);
+      const int bh = r & ((1 << (a.lTH - 1)) - 1); r >>= (a.lTH - 1);
+      const int tt = r & ((1 << a.lTT) - 1);
+      const int tn = r >> a.lTT;
+      p = ((((tn << a.lTT) | tt) << a.lTH | (2 * bh)) << lW) | (2 * bw);
+      wo = tn * a.plane1 + (tt * a.WH + 2 * bh) * a.WW + 2 * bw;
+    };
+    for (int b = 0; b < nbox; ++b) {
+      const float* cur = smem + (b & 1) * stage_floats;
+      __syncthreads();   // barrier b
+      float ya[2][4], dv[2][3][4];
+      auto fetch = [&](int s, float (&Y)[4], float (&D)[3][4]) {
+        int p, wo;
+        offs(s, p, wo);
+        const float* yp = cur + abase + p;
+        Y[0] = yp[0]; Y[1] = yp[1]; Y[2] = yp[TWb]; Y[3] = yp[TWb + 1];
+        const float* xp = cur + jbase + wo + xh * a.WW;          // patch rows xh .. xh + 2
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) D[r][c] = xp[r * a.WW + c];
+      };
+      fetch(0, ya[0], dv[0]);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (s + 1 < 8) fetch(s + 1, ya[(s + 1) & 1], dv[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float (&Y)[4] = ya[s & 1];
+        const float (&D)[3][4] = dv[s & 1];
+        // dM rows of this half (signs deferred): xh = 0: y_row0, y_row0 + y_row1;  xh = 1: y_row0 - y_row1, y_row1
+        float ra[2][2];
+        if (xh == 0) { ra[0][0] = Y[0]; ra[0][1] = Y[1]; ra[1][0] = Y[0] + Y[2]; ra[1][1] = Y[1] + Y[3]; }
+        else         { ra[0][0] = Y[0] - Y[2]; ra[0][1] = Y[1] - Y[3]; ra[1][0] = Y[2]; ra[1][1] = Y[3]; }
+        // B^T d rows of this half: xh = 0: d0 - d2, d1 + d2 (patch rows 0,1,2);  xh = 1: d2 - d1, d1 - d3 (rows 1,2,3)
+        float rb[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (xh == 0) { rb[0][c] = D[0][c] - D[2][c]; rb[1][c] = D[1][c] + D[2][c]; }
+          else         { rb[0][c] = D[1][c] - D[0][c]; rb[1][c] = D[0][c] - D[2][c]; }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const float a0 = ra[ii][0], a1 = ra[ii][1];
+          const float A4[4] = {a0, a0 + a1, a0 - a1, a1};
+          const float B4[4] = {rb[ii][0] - rb[ii][2], rb[ii][1] + rb[ii][2], rb[ii][2] - rb[ii][1],
+                               rb[ii][1] - rb[ii][3]};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            accw[ii][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A4[j], B4[j], accw[ii][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // partial dg of this xi-half: dg = G^T dU G restricted to its two rows; slice 2 * split + xh
+    float* out = a.part + (long)(2 * split + xh) * a.Cout * a.J;
+    const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+      if (co < a.Cout && ci < a.Cin) {
+        float t[2][3];                                   // column pass (over j), s(3) = -1
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const float u0 = accw[ii][0][e], u1 = accw[ii][1][e], u2 = accw[ii][2][e], u3 = accw[ii][3][e];
+          const float hs = 0.5f * (u1 + u2);
+          t[ii][0] = u0 + hs;
+          t[ii][1] = 0.5f * (u1 - u2);
+          t[ii][2] = hs - u3;
+        }
+        float* dst = out + (long)co * a.J + ci * 9;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          // row pass (over i): rows 0,1 (xh = 0): g0 = t0 + t1/2, g1 = t1/2, g2 = t1/2
+          //                    rows 2,3 (xh = 1, row 3 negated): g0 = t2/2, g1 = -t2/2, g2 = t2/2 - t3
+          const float h1 = 0.5f * (xh == 0 ? t[1][kw] : t[0][kw]);
+          if (xh == 0) { dst[kw] = t[0][kw] + h1; dst[3 + kw] = h1; dst[6 + kw] = h1; }
+          else         { dst[kw] = h1; dst[3 + kw] = -h1; dst[6 + kw] = h1 - t[1][kw]; }
+        }
+      }
+    }
+    return;
+  }
   int abase[MB], jb[NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) abase[mb] = ((wm * MB + mb) * 32 + l31) * LDY + half;
@@ -984,6 +1094,31 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
       return 6;
     }
   }
+  if (id == 1 && d->algo == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->ph == 1 && d->pw == 1 &&
+      d->pt == 0 && (d->Ho % 2) == 0 && (d->Wo % 2) == 0 && d->Hi == d->Ho && d->Wi == d->Wo) {
+    // F(2x2,3x3) domain (the layer's forward / data gradient use it: desc.algo = 1): 32 co x 64 ci per
+    // workgroup, boxes of 64 positions = 16 blocks whose pairs are neighbours along w
+    static const bool off = getenv("COCLR_WGRAD_WINO2") && atoi(getenv("COCLR_WGRAD_WINO2")) == 0;
+    ConvPlan q = p;
+    conv_pick_box(&q, 6, 1, 3, 3);
+    const int planeP = q.plane | 1;
+    const size_t stage = ((size_t)32 * 65 + (size_t)64 * planeP) * sizeof(float);
+    const double lim = 2147483648.0;
+    if (!off && q.lTW >= 2 && q.lTH >= 1 && cdiv(q.plane, 64) <= 3 && 2 * stage <= 160 * 1024 &&
+        ((double)(1 << q.lTN) * d->x_nstride + (double)q.Cin * q.Ti * q.Hi * q.Wi) * 4.0 < lim &&
+        ((double)(1 << q.lTN) * d->y_nstride + (double)q.Cout * q.To * q.Ho * q.Wo) * 4.0 < lim) {
+      p = q;
+      w->planeP2 = planeP;
+      w->lds2 = 2 * stage;
+      w->mt2 = cdiv(p.Cout, 32);
+      w->ct2 = cdiv(p.Cin, 64);
+      int S = 512 / (w->mt2 * w->ct2);
+      if (S > p.ntiles / 4) S = p.ntiles / 4;
+      if (S < 1) S = 1;
+      w->S2 = xcd_round(S);
+      return 7;
+    }
+  }
   conv_pick_box(&p, 6, kt, kh, kw);
   if ((id == 4 || id == 5) && p.Ti == 1 && p.Hi == 1 && p.lTW == 6 && p.lTN == 0 &&
       (p.Wi % 64) == 0 && (d->x_nstride % 4) == 0 && (d->y_nstride % 4) == 0) {
@@ -1074,9 +1209,9 @@ int launch_wgrad(WgradArgs& a, const WPlan& w, hipStream_t stream) {
   return 0;
 }
 
-template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false, int NL = 4>
+template <int KT, int KH, int KW, int MB, int NB, int PCH, bool WINO = false, int NL = 4, bool WHW = false>
 int launch_wgrad2(const Wgrad2Args& a, const WPlan& w, hipStream_t stream) {
-  auto kern = conv_wgrad2_kernel<KT, KH, KW, MB, NB, PCH, WINO, NL>;
+  auto kern = conv_wgrad2_kernel<KT, KH, KW, MB, NB, PCH, WINO, NL, WHW>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   hipLaunchKernelGGL(kern, dim3(w.S2, w.ct2, w.mt2), dim3(256 + 64 * NL), w.lds2, stream, a);
@@ -1090,8 +1225,9 @@ extern "C" int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* e
   WPlan w;
   int rc = plan_wgrad(d, &w);
   if (rc) return rc;
-  *elems = (int64_t)(w.v2 ? w.S2 * (w.v2 == 9 ? 4 : 1) : w.S) * d->Cout * d->Cin * d->kt * d->kh *
-           d->kw;
+  // split slices: the stem kernel writes four per split (one per matrix wave), the F(2x2,3x3) form two
+  *elems = (int64_t)(w.v2 ? w.S2 * (w.v2 == 9 ? 4 : (w.v2 == 7 ? 2 : 1)) : w.S) * d->Cout * d->Cin * d->kt *
+           d->kh * d->kw;
   return 0;
 }
 
@@ -1182,6 +1318,8 @@ extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x
       case 4: rc = launch_wgrad2<1, 1, 1, 2, 2, 2>(a, w, stream); break;
       case 5: rc = launch_wgrad2<1, 1, 1, 1, 1, 2>(a, w, stream); break;
       case 6: rc = launch_wgrad2<4, 1, 1, 1, 1, 2, true, 8>(a, w, stream); break;
+      case 7: rc = pch <= 2 ? launch_wgrad2<1, 3, 3, 1, 1, 2, false, 4, true>(a, w, stream)
+                            : launch_wgrad2<1, 3, 3, 1, 1, 3, false, 4, true>(a, w, stream); break;
       case 9: {
         auto kern = conv_wgrad_stem_kernel<7, 7, 3, 20>;
         static std::atomic<uint64_t> attr_done{0};
@@ -1194,7 +1332,7 @@ extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x
       default: rc = COCLR_EINVAL;
     }
     if (rc) return rc;
-    S_used = w.S2 * (w.v2 == 9 ? 4 : 1);
+    S_used = w.S2 * (w.v2 == 9 ? 4 : (w.v2 == 7 ? 2 : 1));
   } else {
     const ConvPlan& p = w.p;
     WgradArgs a;

@@ -737,3 +737,48 @@ def _pack_elems(args, kw):
     if kw:
         return taps * r * c
     return taps * ((r + 31) // 32 * 32) * ((c + 127) // 128 * 128)
+
+
+WINO_HW_WGRAD_CASES = [(2, 64, 192, (2, 32, 32)), (2, 192, 208, (4, 16, 16)), (3, 48, 96, (3, 8, 8)),
+                       (5, 160, 320, (2, 8, 8)), (2, 96, 128, (3, 16, 16)), (2, 130, 70, (2, 12, 20)),
+                       (3, 64, 50, (1, 4, 4)), (32, 64, 192, (1, 32, 32))]
+
+
+@pytest.mark.parametrize("case", WINO_HW_WGRAD_CASES, ids=lambda c: "%d_%d_%d_%s" % c)
+def test_conv_spatial_winograd_weight_gradient(case, monkeypatch):
+    """Weight gradient of the wide (1,3,3) layers in the F(2x2,3x3) domain (desc.algo = 1, >= 48 channels
+    both ways: 16 MFMAs per two 2x2 blocks instead of 36, ABI 15): against ATen's fp32 CPU gradient, the
+    accumulate form, a dY channel slice, run-to-run bit-identity, and against the direct kernel on the
+    same data (algo = 0)."""
+    from coclr_amd import ops
+    N, Cin, Cout, dims = case
+    k, s, p = (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    torch.manual_seed(17)
+    x = torch.randn(N, Cin, *dims)
+    w = (torch.randn(Cout, Cin, *k) * 0.05).requires_grad_(True)
+    ref = F.conv3d(x, w, None, s, p)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    g = ops.ConvGeom(N, Cin, Cout, dims, k, s, p, algo=1)
+    g0 = ops.ConvGeom(N, Cin, Cout, dims, k, s, p, algo=0)
+    # two split slices per split in the Winograd form (one per xi-half): the planner reports them
+    assert g.wgrad_workspace() % (Cout * Cin * 9) == 0
+    xd, dyd = dev(x), dev(dy)
+    dw = torch.full((Cout, Cin, *k), float("nan"), device="cuda")
+    ws = torch.empty(g.wgrad_workspace(), device="cuda")
+    ops.conv_wgrad(g, xd, dyd, dw, ws, Cin * 9, 9, 0)
+    close(dw, w.grad, what="winograd-domain wgrad")
+    dw0 = torch.empty_like(dw)
+    ws0 = torch.empty(g0.wgrad_workspace(), device="cuda")
+    ops.conv_wgrad(g0, xd, dyd, dw0, ws0, Cin * 9, 9, 0)
+    close(dw, dw0, rtol=2e-5, what="winograd-domain vs direct wgrad")
+    ops.conv_wgrad(g, xd, dyd, dw, ws, Cin * 9, 9, 0, accumulate=True)
+    close(dw, 2 * w.grad, what="winograd-domain wgrad accumulate")
+    wide = torch.zeros(N, Cout + 5, *dims, device="cuda")
+    wide[:, 3:3 + Cout] = dyd
+    ops.conv_wgrad(g, xd, wide[:, 3:3 + Cout], dw, ws, Cin * 9, 9, 0)
+    close(dw, w.grad, what="winograd-domain wgrad from a dY slice")
+    # run-to-run determinism (fixed fold order of the split slices)
+    dw2 = torch.empty_like(dw)
+    ops.conv_wgrad(g, xd, wide[:, 3:3 + Cout], dw2, ws, Cin * 9, 9, 0)
+    assert torch.equal(dw, dw2)
