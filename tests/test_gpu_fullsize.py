@@ -39,7 +39,19 @@ def _geometries(network):
             order.append(key)
         return inner(geom, *a, **kw)
 
-    ops.conv_fwd = rec
+    inner_multi = ops.conv_fwd_multi
+
+    def rec_multi(calls):
+        # sibling units emitted in lockstep come through the multi entry point
+        for c in calls:
+            geom = c["geom"]
+            key = (geom.Cin, geom.Cout, geom.idim, geom.k, geom.s, geom.p, geom.odim)
+            if key not in seen:
+                seen.add(key)
+                order.append(key)
+        return inner_multi(calls)
+
+    ops.conv_fwd, ops.conv_fwd_multi = rec, rec_multi
     try:
         torch.manual_seed(0)
         net, _ = select_backbone(network)
@@ -47,7 +59,7 @@ def _geometries(network):
         with torch.no_grad():
             net(torch.randn(B, 3, 32, 128, 128, device="cuda"))
     finally:
-        ops.conv_fwd = inner
+        ops.conv_fwd, ops.conv_fwd_multi = inner, inner_multi
     del net
     torch.cuda.empty_cache()
     return order
