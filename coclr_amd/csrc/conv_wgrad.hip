@@ -1094,13 +1094,28 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
       return 6;
     }
   }
-  if (id == 1 && d->algo == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->ph == 1 && d->pw == 1 &&
-      d->pt == 0 && (d->Ho % 2) == 0 && (d->Wo % 2) == 0 && d->Hi == d->Ho && d->Wi == d->Wo) {
-    // F(2x2,3x3) domain (the layer's forward / data gradient use it: desc.algo = 1): 32 co x 64 ci per
-    // workgroup, boxes of 64 positions = 16 blocks whose pairs are neighbours along w
-    static const bool off = getenv("COCLR_WGRAD_WINO2") && atoi(getenv("COCLR_WGRAD_WINO2")) == 0;
+  // COCLR_WGRAD_WINO2: 0 never, 1 (default) the layers whose forward is Winograd (desc.algo = 1: maps of 16x16
+  // and up), 2 every wide (1,3,3) stride-1 'same' layer on an even map
+  static const int wino2_mode = getenv("COCLR_WGRAD_WINO2") ? atoi(getenv("COCLR_WGRAD_WINO2")) : 1;
+  if (id == 1 && (d->algo == 1 || wino2_mode >= 2) && d->st == 1 && d->sh == 1 && d->sw == 1 && d->ph == 1 &&
+      d->pw == 1 && d->pt == 0 && (d->Ho % 2) == 0 && (d->Wo % 2) == 0 && d->Hi == d->Ho && d->Wi == d->Wo) {
+    // F(2x2,3x3) domain: 32 co x 64 ci per workgroup, boxes of 64 positions = 16 blocks whose pairs are
+    // neighbours along w
+    const bool off = wino2_mode <= 0;
     ConvPlan q = p;
     conv_pick_box(&q, 6, 1, 3, 3);
+    if (q.lTW == 5 && q.lTH == 1 && q.lTT == 0 && q.lTN == 0 && q.Ho >= 4) {
+      // 32 x 2 boxes stage a 34 x 4 window (three LDS-DMA pieces per channel); 16 x 4 boxes an 18 x 6 one
+      // (two pieces): with 16 MFMAs per block pair instead of 36 the loader waves are what paces this
+      // kernel, and a third fewer window pieces is a third less of their work
+      q.lTW = 4; q.lTH = 2;
+      q.nbw = cdiv(q.Wo, 16); q.nbh = cdiv(q.Ho, 4);
+      q.ntiles = q.nbw * q.nbh * q.nbt * q.nbn;
+      q.nboxes = q.ntiles;
+      q.WH = 3 + 3; q.WW = 15 + 3;
+      q.plane1 = q.WT * q.WH * q.WW;
+      q.plane = q.plane1;
+    }
     const int planeP = q.plane | 1;
     const size_t stage = ((size_t)32 * 65 + (size_t)64 * planeP) * sizeof(float);
     const double lim = 2147483648.0;
