@@ -295,11 +295,11 @@ def nce_roofline(device, B):
            "algorithmic_mb_per_launch": round(byts / 1e6, 2),
            "tflops": round(flop / us / 1e6, 2),
            "mfma_frac_of_fp32_peak": round(flop / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 4)}
-    pj = os.path.join(ROOT, "profiles", "r03_nce_pmc.json")
-    if not os.path.exists(pj):
-        pj = os.path.join(ROOT, "profiles", "r02_nce_pmc.json")
-    if os.path.exists(pj):
-        rec["pmc"] = json.load(open(pj))
+    for tag in ("r04", "r03", "r02"):
+        pj = os.path.join(ROOT, "profiles", tag + "_nce_pmc.json")
+        if os.path.exists(pj):
+            rec["pmc"] = json.load(open(pj))
+            break
     return rec
 
 
@@ -585,9 +585,8 @@ def main():
         issued = flops * 16.0 / 36.0                             # F(2x2,3x3): 16 of 36 products
         roof = None
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = next((t for t in (os.path.join(ROOT, "profiles", tag + "_traffic.json")
+                                  for tag in ("r04", "r03", "r02")) if os.path.exists(t)), "")
         if os.path.exists(tpath) and args.net == "s3d" and B == 32:
             # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
             # (counters cannot be read from inside the process)

@@ -26,7 +26,7 @@ def timeit(fn, reps=REPS):
 
 print("%-8s | %10s %8s %8s | %10s | %10s %10s" % ("K", "logits us", "GFLOP/s", "GB/s", "bwd us",
                                                  "sim us", "mask us"))
-for K in (2048, 16384):
+for K in [int(v) for v in os.environ.get("KS", "2048,16384").split(",")]:
     torch.manual_seed(0)
     q = F.normalize(torch.randn(B, D, device=dev), dim=1)
     k = F.normalize(torch.randn(B, D, device=dev), dim=1)
