@@ -24,12 +24,15 @@ us = durs[len(durs) // 2] / 1e3 if durs else None
 B, D, K = 32, 128, 16384
 flop = 2.0 * B * D * K
 byts = 4.0 * (D * K + 2 * B * D + B * (1 + K))
-cycles_per_xcd = val["GRBM_GUI_ACTIVE"] / 8.0
-busy = val["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cycles_per_xcd)
+# SIMD cycles from the kernel's traced duration at the 2.2 GHz the chip sustains (as in r02): GRBM_GUI_ACTIVE of a
+# 7-8 us launch under a counter pass is dominated by dispatch overhead
+simd_cycles = 1024.0 * (us or 0.0) * 1e-6 * 2.2e9
+busy = val["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles if simd_cycles else 0.0
 out = {"source": "profiles/%s (rocprofv3 --pmc, separate passes, tools/pmc_layers.sh with PMC_SCRIPT=tools/bench_nce.py "
                  "KS=16384; kernel duration = median of the same runs' kernel trace)" % os.path.basename(src),
        "kernel": "nce_logits_kernel<128>, B=32, K=16384 launch (256 workgroups)",
        "kernel_duration_us": us, "mfma_busy_frac": round(busy, 4),
+       "mfma_busy_cycles_per_launch": val["SQ_VALU_MFMA_BUSY_CYCLES"], "simd_cycles_per_launch": round(simd_cycles),
        "tflops": round(flop / us / 1e6, 2) if us else None,
        "frac_of_fp32_mfma_peak": round(flop / us / 1e6 / 157.3, 4) if us else None,
        "algorithmic_gbs": round(byts / us / 1e3, 1) if us else None,
