@@ -75,6 +75,12 @@ def parse():
     ap.add_argument("--hang-timeout", type=float, default=240.0,
                     help="world > 1: seconds without progress (no new collective, no new step) after "
                          "which a rank reports the exchange it is stuck in and the job ends")
+    ap.add_argument("--one-gpu-rehearsal", action="store_true",
+                    help="world > 1 with EVERY rank on cuda:0 over gloo (RCCL refuses two ranks on one device): "
+                         "the N > 1 bench path -- DDP, bucket hook, per-stage nodes, routed exchange, checked "
+                         "step, instrumented collectives -- with the real kernels; only valid under "
+                         "tests/bench_rehearse_gpu.py, which stages device payloads of the two collectives "
+                         "gloo cannot carry through the host; never a measurement")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="intra-op threads of the CPU baseline (16 is the fastest on the 128-core "
@@ -323,6 +329,14 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=max(60.0, 2 * args.hang_timeout)))
         torch.cuda.synchronize = lambda *a, **k: None
+        args.no_extra_legs = args.no_cpu_baseline = True
+    elif args.one_gpu_rehearsal:
+        local_rank = 0
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=max(60.0, 2 * args.hang_timeout)))
         args.no_extra_legs = args.no_cpu_baseline = True
     else:
         torch.cuda.set_device(local_rank)
@@ -651,7 +665,9 @@ def main():
             "value": round(clips, 2), "unit": "clips/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
-            "data": "synthetic" if not dry else "DRY RUN ON THE HOST (ATen double, not a measurement)",
+            "data": "synthetic" if not (dry or args.one_gpu_rehearsal) else
+                    ("DRY RUN ON THE HOST (ATen double, not a measurement)" if dry else
+                     "REHEARSAL: every rank on ONE GPU over gloo (real kernels, not a measurement)"),
             "config": {"workload": "%s %s moco-k=%d seq_len=%d img=%d bs=%d/GPU, DDP(nccl=RCCL) x%d, "
                                    "fwd + loss + top-1/5 + bwd + Adam(lr 1e-3, wd 1e-5) over %d "
                                    "single-tensor param groups (main_nce.py:190-200)"
