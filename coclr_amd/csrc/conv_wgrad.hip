@@ -379,6 +379,12 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
                                      iw) * 4)
                        : W2_OOB;
         }
+#ifdef COCLR_WGRAD_ABLATE
+        // timing ablation (wrong results by design; tools/wgrad_ablate.sh): no window DMA after the first
+        // two boxes.  Measured at B=32: Conv_2c.conv1 (F(2x2,3x3) form) 0.713 -> 0.704 ms, Conv_2c.conv2
+        // (F(2,3) form) 0.883 -> 0.815, Conv_1a.conv2 1.038 -> 1.016: the loader waves do not pace these kernels
+        if (b >= 2) goto loaded;
+#endif
         for (int c = lw; c < BCt; c += NL) {
           const int ci = ci0 + c;
           if (ci < a.Cin) {
@@ -395,6 +401,9 @@ conv_wgrad2_kernel(const Wgrad2Args a) {
           }
         }
       }
+#ifdef COCLR_WGRAD_ABLATE
+      loaded:;
+#endif
       __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of box b is in LDS
       __syncthreads();                      // barrier b
     }
