@@ -276,6 +276,10 @@ class S3D(_Emitter):
             groups = self.__dict__["_coclr_groups"] = [
                 _Group(list(self.block1) + b2[:1]), _Group(b2[1:] + b3[:1]), _Group(b3[1:] + b4[:1]),
                 _Group(b4[1:] + b5[:1]), _Group(b5[1:])]
+            # every node but the one that runs LAST in backward (stage 1) may leave the weight-gradient
+            # stream un-joined when its gradients live in DDP's buckets (engine.Run.defer_side)
+            for grp in groups[1:]:
+                grp.__dict__["_coclr_defer_join"] = True
         return groups
 
     def _late_split(self):

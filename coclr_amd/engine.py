@@ -68,6 +68,16 @@ def _probe_relu(bn, y, scale, shift, residual=None):
 
 
 _SIDE = {}
+_PENDING_SIDE = {}    # device -> tensors read by weight-gradient kernels of nodes that deferred their join
+DEFER_JOIN = os.environ.get("COCLR_DEFER_JOIN", "1") != "0"
+DEFERRED = [0]        # nodes that left the stream un-joined (tests / bench read it)
+
+
+def side_stream_of(device):
+    """The weight-gradient stream of `device`, if any work was ever put on it."""
+    return _SIDE.get(device)
+
+
 _SIDE_PRIORITY = int(os.environ.get("COCLR_WGRAD_PRIORITY", "0"))
 # weight-gradient closures per release window (Run.side_stream); 0 = hold everything until join_side
 _SIDE_WINDOW = int(os.environ.get("COCLR_SIDE_WINDOW", "12"))
@@ -351,7 +361,8 @@ class Run:
             self._open = []
 
     # -- backward ----------------------------------------------------------------
-    def backward(self, dout):
+    def backward(self, dout, defer_join=False):
+        """defer_join: this node may leave the weight-gradient stream un-joined (see defer_side)."""
         out = self.out
         self.grads[id(out.base)] = dout.contiguous()
         # closures run in reverse emission order; closures of different lanes between two
@@ -380,7 +391,11 @@ class Run:
             cur = torch.cuda.current_stream(self.device)
             for st in started.values():
                 cur.wait_stream(st)
-        self.join_side()
+        if defer_join and self._side_used and self.param_grads and \
+                all(k in self._slots_out for k in self.param_grads):
+            self.defer_side()
+        else:
+            self.join_side()
         return self.grads
 
     # Weight gradients feed nothing inside the backward pass (only the optimiser), so they
@@ -418,11 +433,31 @@ class Run:
         return st
 
     def join_side(self):
-        if self._side_used:
+        pending = _PENDING_SIDE.pop(self.device, None)
+        if self._side_used or pending:
             torch.cuda.current_stream(self.device).wait_stream(_SIDE[self.device])
             self._side_used = False
         self._side_keep = []
         self._side_windows = []
+
+    def defer_side(self):
+        """Leave the weight-gradient stream un-joined at the end of an intermediate autograd node.
+
+        With the backbone as one node per stage (world > 1) every node used to end with a join: the next
+        stage's data-gradient chain then waited for this stage's weight gradients.  Nothing on the main
+        stream needs them: when EVERY parameter gradient of the node was written into DistributedDataParallel's
+        bucket views (grad_out), autograd only adopts aliases (no kernel reads them) and the bucket hook
+        (coclr_amd/parallel.py) makes the all-reduce wait for the weight-gradient stream itself.  The last
+        node of the backward pass (stage 1) joins as before, which also orders everything in front of the
+        optimiser.  What the side kernels read stays referenced until then."""
+        DEFERRED[0] += 1
+        keep = _PENDING_SIDE.setdefault(self.device, [])
+        keep.extend(self._side_keep)
+        for _, ts in self._side_windows:
+            keep.extend(ts)
+        self._side_keep = []
+        self._side_windows = []
+        self._side_used = False
 
     # -- weight packing ------------------------------------------------------------
     def _packed_buffer(self, owner, tag, n, zero):
@@ -1061,6 +1096,7 @@ class EngineFn(torch.autograd.Function):
         ctx.xin = xin
         ctx.params = params
         ctx.need_dx = need_dx
+        ctx.module_defer = getattr(module, "__dict__", {}).get("_coclr_defer_join", False)
         out = run.out.view()
         # A FRESH tensor object: autograd stamps what we return with grad_fn, and grad_fn -> ctx
         # -> run -> tape closures -> run.out.  Returning run.out's own tensor would close that
@@ -1075,7 +1111,7 @@ class EngineFn(torch.autograd.Function):
         if run is None:
             raise RuntimeError("coclr_amd: backbone backward called twice (graph not retained)")
         ctx.run = None
-        run.backward(dout)
+        run.backward(dout, defer_join=DEFER_JOIN and bool(ctx.module_defer))
         dx = run.grads.pop(id(ctx.xin.base), None) if ctx.need_dx else None
         # Hand the gradients over WITHOUT keeping a reference: AccumulateGrad takes a freshly
         # produced gradient as .grad only when nobody else holds it, and clones it otherwise --

@@ -52,6 +52,7 @@ _installed = [False]
 #     recorded as (name, bytes, milliseconds): an instrumented, serialised step -- never the timed region.
 LAST = ["", 0.0, 0]
 TIMINGS = None
+_PREP = {}            # device -> stream on which bucket pre-division + all-reduce are enqueued
 
 
 def collective(name, fn, nbytes=0, device=None):
@@ -133,10 +134,27 @@ def bucket_hook(state, bucket):
         fut = torch.futures.Future()
         fut.set_result(buf)
         return fut
-    buf.div_(world)
-    work = collective("ddp bucket %d all_reduce (parallel.bucket_hook; main_nce.py:172)" % idx,
-                      lambda: dist.all_reduce(buf, group=group, async_op=True),
-                      buf.numel() * buf.element_size(), buf.device)
+    # The bucket's gradients are written by weight-gradient kernels on the engine's side stream, and
+    # intermediate stage nodes no longer join that stream on the main one (engine.Run.defer_side): the
+    # pre-division and the all-reduce are ordered behind BOTH streams on a third one, so the main stream's
+    # data-gradient chain never waits for a weight gradient.
+    side = engine.side_stream_of(buf.device) if buf.is_cuda else None
+    if side is None:
+        buf.div_(world)
+        work = collective("ddp bucket %d all_reduce (parallel.bucket_hook; main_nce.py:172)" % idx,
+                          lambda: dist.all_reduce(buf, group=group, async_op=True),
+                          buf.numel() * buf.element_size(), buf.device)
+    else:
+        prep = _PREP.get(buf.device)
+        if prep is None:
+            prep = _PREP[buf.device] = torch.cuda.Stream(device=buf.device)
+        prep.wait_stream(torch.cuda.current_stream(buf.device))
+        prep.wait_stream(side)
+        with torch.cuda.stream(prep):
+            buf.div_(world)
+            work = collective("ddp bucket %d all_reduce (parallel.bucket_hook; main_nce.py:172)" % idx,
+                              lambda: dist.all_reduce(buf, group=group, async_op=True),
+                              buf.numel() * buf.element_size(), buf.device)
     return work.get_future().then(lambda f: f.value()[0])
 
 

@@ -368,6 +368,8 @@ def test_gradients_in_ddp_buckets_bit_identical_and_deterministic(monkeypatch):
     engine.Run.grad_out).  On the HIP kernels, under a 1-rank RCCL group, at the small golden shape:
       * from the third step on every backbone `.grad` IS its bucket view (DDP then skips its
         per-parameter `aten::mul` copy: tools/find_copies.py counts them);
+      * with one autograd node per stage, intermediate nodes defer the weight-gradient stream's join
+        (engine.Run.defer_side) and the parameters are still bit-identical;
       * parameters after four Adam steps are BIT-IDENTICAL to the run with COCLR_DDP_HOOK=0 (DDP's own
         per-parameter path) -- which also proves the backward pass run-to-run deterministic (no float
         atomics anywhere: the pooling backward accumulates in fixed colour-class order)."""
@@ -380,8 +382,11 @@ def test_gradients_in_ddp_buckets_bit_identical_and_deterministic(monkeypatch):
         os.environ.setdefault("MASTER_PORT", "29611")
         dist.init_process_group("nccl", rank=0, world_size=1)
 
-    def run(hook):
+    from coclr_amd.backbone import s3dg
+
+    def run(hook, split=False):
         monkeypatch.setenv("COCLR_DDP_HOOK", "1" if hook else "0")
+        monkeypatch.setattr(s3dg, "_SPLIT_MODE", "1" if split else "0")
         engine._GRAD_SLOTS.clear()
         torch.manual_seed(0)
         model = product.InfoNCE('s3d', 128, 32, 0.999, 0.07).cuda()
@@ -417,6 +422,15 @@ def test_gradients_in_ddp_buckets_bit_identical_and_deterministic(monkeypatch):
         nparams = len(list(model.encoder_q[0].parameters()))
         assert aliased[-1] == nparams and aliased[-2] == nparams, (aliased, nparams)
         for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+        # one autograd node per backbone stage (the structure at world > 1): stages 5..2 leave the
+        # weight-gradient stream un-joined once their gradients live in the buckets (engine.Run.defer_side);
+        # the result does not move by a bit
+        before = engine.DEFERRED[0]
+        got2, aliased2, _ = run(True, split=True)
+        assert aliased2[-1] == nparams
+        assert engine.DEFERRED[0] - before >= 4 * 2, "stages 2-5 should have deferred in steps 3 and 4"
+        for a, b in zip(ref, got2):
             assert torch.equal(a, b)
     finally:
         engine._GRAD_SLOTS.clear()
