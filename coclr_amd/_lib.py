@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -34,7 +34,8 @@ class ConvCall(C.Structure):
     """Mirror of `coclr_conv_call` (one problem of coclr_conv3d_fwd_multi)."""
     _fields_ = [("d", C.POINTER(ConvDesc)), ("x", vp), ("w_packed", vp), ("y", vp), ("stats", vp),
                 ("bias", vp), ("ep_scale", vp), ("ep_shift", vp), ("n_index", vp), ("relu", i32),
-                ("accumulate", i32)]
+                ("accumulate", i32), ("bwd_y", vp), ("bwd_scale", vp), ("bwd_shift", vp), ("bwd_mean", vp),
+                ("bwd_invstd", vp), ("bwd_relu", i32), ("reserved", i32)]
 
 
 class BnFwdCall(C.Structure):
@@ -50,7 +51,7 @@ class BnBwdCall(C.Structure):
     _fields_ = [(n, vp) for n in ("dz", "y", "scale", "shift", "mean", "invstd", "sums_ws", "dy", "dgamma",
                                   "dbeta")] + [
         ("S", i64), ("dz_nstride", i64), ("y_nstride", i64), ("dy_nstride", i64), ("N", i32), ("C", i32),
-        ("relu", i32), ("training", i32)]
+        ("relu", i32), ("training", i32), ("part", vp * 2), ("part_ntiles", i32 * 2)]
 
 
 _P = C.POINTER
@@ -62,6 +63,7 @@ _SIGNATURES = {
                                  _P(i64), _P(i32)],
     "coclr_conv_pack_batch": [vp, vp, i32, vp],
     "coclr_conv3d_ntiles": [_P(ConvDesc), _P(i32)],
+    "coclr_conv3d_bwd_sums_ok": [_P(ConvDesc), _P(i32)],
     "coclr_conv3d_fwd": [_P(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "coclr_conv3d_fwd_multi": [_P(ConvCall), i32, vp],
     "coclr_conv3d_wgrad_workspace": [_P(ConvDesc), _P(i64)],

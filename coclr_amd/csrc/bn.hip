@@ -171,6 +171,29 @@ bn_act_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__
   }
 }
 
+// The reduction done elsewhere: the data gradient(s) that wrote dz left (sum g, sum g*xhat) per channel
+// and output tile in float ([2][C][ntiles], coclr_conv_call.bwd_y); fold them in fp64, fixed order, into
+// the one-group form the apply pass reads.
+__global__ void __launch_bounds__(256)
+bn_bwd_fold_kernel(const float* __restrict__ p0, int n0, const float* __restrict__ p1, int n1, int C,
+                   double* sums) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  double sg = 0.0, sgx = 0.0;
+  for (int i = threadIdx.x; i < n0; i += 256) {
+    sg += (double)p0[(long)c * n0 + i];
+    sgx += (double)p0[((long)C + c) * n0 + i];
+  }
+  if (p1)
+    for (int i = threadIdx.x; i < n1; i += 256) {
+      sg += (double)p1[(long)c * n1 + i];
+      sgx += (double)p1[((long)C + c) * n1 + i];
+    }
+  sg = block256_sum_d(sg, red);
+  sgx = block256_sum_d(sgx, red);
+  if (threadIdx.x == 0) { sums[(long)c * 2] = sg; sums[(long)c * 2 + 1] = sgx; }
+}
+
 // Apply pass: folds the per-group partial sums of its channel (fp64), derives
 //   training: dy = A*g + Bc*y + D  with  A = scale, Bc = -scale*invstd*mgx,
 //             D = scale*(mean*invstd*mgx - mg);  eval: dy = scale*g
@@ -762,6 +785,34 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
   return 0;
 }
 
+namespace {
+// BatchNorm(+ReLU) backward of a unit whose sums the producing data gradient already formed: fold + apply
+int bn_backward_from_partials(const coclr_bn_bwd_call& c, hipStream_t stream) {
+  if (!c.sums_ws || c.part_ntiles[0] <= 0 || (c.part[1] && c.part_ntiles[1] <= 0)) return COCLR_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(c.C), dim3(256), 0, stream, c.part[0], c.part_ntiles[0],
+                     c.part[1], c.part[1] ? c.part_ntiles[1] : 0, c.C, c.sums_ws);
+  COCLR_LAUNCH_CHECK();
+  const bool vec = (c.S % 4 == 0) && (c.dz_nstride % 4 == 0) && (c.y_nstride % 4 == 0) &&
+                   (c.dy_nstride % 4 == 0);
+  const double count = (double)c.N * (double)c.S;
+  dim3 grid = plane_grid(c.N, c.C, (int)c.S);
+  const float* nof = nullptr;
+  float* nod = nullptr;
+  if (vec)
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, grid, dim3(256), 0, stream, c.dz, c.y, nof, c.scale,
+                       c.shift, c.mean, c.invstd, c.sums_ws, 1, count, c.training, c.dgamma, c.dbeta, c.dy, nod,
+                       c.N, c.C, (int)c.S, (long)c.dz_nstride, (long)c.y_nstride, (long)c.dy_nstride, 0L, 0L,
+                       c.relu, 0);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, grid, dim3(256), 0, stream, c.dz, c.y, nof, c.scale,
+                       c.shift, c.mean, c.invstd, c.sums_ws, 1, count, c.training, c.dgamma, c.dbeta, c.dy, nod,
+                       c.N, c.C, (int)c.S, (long)c.dz_nstride, (long)c.y_nstride, (long)c.dy_nstride, 0L, 0L,
+                       c.relu, 0);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
 extern "C" int coclr_bn_act_backward_multi(const coclr_bn_bwd_call* calls, int n, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!calls || n < 1) return COCLR_EINVAL;
@@ -780,7 +831,7 @@ extern "C" int coclr_bn_act_backward_multi(const coclr_bn_bwd_call* calls, int n
       const bool small = (long)c.N * c.S <= kSmallChannel;
       const bool vec = (c.S % 4 == 0) && (c.dz_nstride % 4 == 0) && (c.y_nstride % 4 == 0) &&
                        (c.dy_nstride % 4 == 0);
-      if (!small || !fuse) break;
+      if (!small || !fuse || c.part[0]) break;
       if (t.n == 0) vec0 = vec;
       else if (vec != vec0) break;
       BnBwdUnit& u = t.u[t.n++];
@@ -800,6 +851,12 @@ extern "C" int coclr_bn_act_backward_multi(const coclr_bn_bwd_call* calls, int n
       continue;
     }
     const coclr_bn_bwd_call& c = calls[i];
+    if (c.part[0]) {
+      int rc = bn_backward_from_partials(c, stream);
+      if (rc) return rc;
+      ++i;
+      continue;
+    }
     int rc = coclr_bn_act_backward(c.dz, c.y, nullptr, c.scale, c.shift, c.mean, c.invstd, c.sums_ws, c.dy,
                                    nullptr, c.dgamma, c.dbeta, c.N, c.C, c.S, c.dz_nstride, c.y_nstride,
                                    c.dy_nstride, 0, 0, c.relu, c.training, 0, stream_);

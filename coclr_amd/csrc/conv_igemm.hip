@@ -56,6 +56,14 @@ struct ConvArgs {
   const float* ep_scale; // [Cout] or nullptr
   const float* ep_shift; // [Cout] or nullptr
   const int64_t* n_index;// optional gather of input samples
+  // data gradient that lands in the dz of a BatchNorm(+ReLU) unit: the unit's conv output (laid out like
+  // y) and coefficients; the statistics slots then receive (sum g, sum g*xhat) of that unit's backward
+  const float* bwd_y;
+  const float* bwd_scale;
+  const float* bwd_shift;
+  const float* bwd_mean;
+  const float* bwd_invstd;
+  int bwd_relu;
   long x_nstride, y_nstride;
   int x_cstride, y_cstride;
   int N, Cin, Cout, CinP, CoutP;
@@ -414,7 +422,58 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bid, cons
       }
     }
   };
-  if (a.accumulate) emit(std::true_type{}); else emit(std::false_type{});
+  // The destination is the dz of a BatchNorm(+ReLU) unit (a.bwd_y = that unit's conv output): store dz and
+  // form the unit's backward sums -- g = dz where its ReLU passed, (sum g, sum g*xhat) -- from the values
+  // in registers, in the arithmetic of bn_act_bwd_reduce_kernel (csrc/bn.hip), whose pass over dz and y
+  // this replaces by one read of y here (aten::native_batch_norm_backward's reduction, threshold_backward).
+  auto emit_bwd = [&]() {
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.bwd_y + (long)n0 * a.y_nstride), 0, BUF_RANGE, 0x00020000);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      float yv[16][NF];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);
+        const bool cok = cout0 + rowu + 4 * half < a.Cout;
+        const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          yv[i][nf] = __uint_as_float(
+              __builtin_amdgcn_raw_buffer_load_b32(rb, cok ? yvoff[nf] : OOB, soff, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);
+        const int ml = rowu + 4 * half;
+        const int co = cout0 + ml;
+        const bool cok = co < a.Cout;
+        const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+        float bsc = 0.f, bsf = 0.f, mu = 0.f, is = 0.f;
+        if (cok) { bsc = a.bwd_scale[co]; bsf = a.bwd_shift[co]; mu = a.bwd_mean[co]; is = a.bwd_invstd[co]; }
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const float v = acc[mf][nf][i];
+          const float u = yv[i][nf];
+          const bool on = pvalid[nf] && (!a.bwd_relu || fmaf(u, bsc, bsf) > 0.f);
+          const float g = on ? v : 0.f;
+          s += g; ss += g * ((u - mu) * is);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, cok ? yvoff[nf] : OOB, soff, 0);
+        }
+        s = row16_sum(s);
+        ss = row16_sum(ss);
+        if ((lane & 15) == 0) {
+          const int slot = wn * 2 + (l31 >> 4);
+          red[(slot * BM + ml) * 2 + 0] = s;
+          red[(slot * BM + ml) * 2 + 1] = ss;
+        }
+      }
+    }
+  };
+  if (a.bwd_y) emit_bwd();
+  else if (a.accumulate) emit(std::true_type{});
+  else emit(std::false_type{});
 
   if (want_stats) {
     __syncthreads();
@@ -738,7 +797,71 @@ __device__ __forceinline__ void conv_wino_t_body(const ConvArgs& a, int bid, con
       }
     }
   };
-  if (a.accumulate) emit(std::true_type{}); else emit(std::false_type{});
+  // see conv_igemm_body: the destination is the dz of a BatchNorm(+ReLU) unit, its backward sums are
+  // formed here from the two frames in registers
+  auto emit_bwd = [&]() {
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.bwd_y + (long)n0 * a.y_nstride), 0, BUF_RANGE, 0x00020000);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+      for (int i0 = 0; i0 < 16; i0 += 4) {
+        float yv[4][NF][2];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = i0 + ii;
+          const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);
+          const bool cok = cout0 + rowu + 4 * half < a.Cout;
+          const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const unsigned vo0 = cok ? yvoff[nf] : OOB;
+            const unsigned vo1 = (cok && p2valid[nf]) ? yvoff[nf] + frame_bytes : OOB;
+            yv[ii][nf][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vo0, soff, 0));
+            yv[ii][nf][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vo1, soff, 0));
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = i0 + ii;
+          const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);
+          const int ml = rowu + 4 * half;
+          const int co = cout0 + ml;
+          const bool cok = co < a.Cout;
+          const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+          float bsc = 0.f, bsf = 0.f, mu = 0.f, is = 0.f;
+          if (cok) { bsc = a.bwd_scale[co]; bsf = a.bwd_shift[co]; mu = a.bwd_mean[co]; is = a.bwd_invstd[co]; }
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const float m0 = acc[mf][nf][0][i], m1 = acc[mf][nf][1][i], m2 = acc[mf][nf][2][i],
+                        m3 = acc[mf][nf][3][i];
+            const float v0 = (m0 + m1) + m2, v1 = (m1 - m2) - m3;
+            const unsigned vo0 = cok ? yvoff[nf] : OOB;
+            const unsigned vo1 = (cok && p2valid[nf]) ? yvoff[nf] + frame_bytes : OOB;
+            const float u0 = yv[ii][nf][0], u1 = yv[ii][nf][1];
+            const bool on0 = pvalid[nf] && (!a.bwd_relu || fmaf(u0, bsc, bsf) > 0.f);
+            const bool on1 = p2valid[nf] && (!a.bwd_relu || fmaf(u1, bsc, bsf) > 0.f);
+            const float g0 = on0 ? v0 : 0.f, g1 = on1 ? v1 : 0.f;
+            s += g0 + g1;
+            ss += g0 * ((u0 - mu) * is) + g1 * ((u1 - mu) * is);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), ry, vo0, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), ry, vo1, soff, 0);
+          }
+          s = row16_sum(s);
+          ss = row16_sum(ss);
+          if ((lane & 15) == 0) {
+            const int slot = wn * 2 + (l31 >> 4);
+            red[(slot * BM + ml) * 2 + 0] = s;
+            red[(slot * BM + ml) * 2 + 1] = ss;
+          }
+        }
+      }
+    }
+  };
+  if (a.bwd_y) emit_bwd();
+  else if (a.accumulate) emit(std::true_type{});
+  else emit(std::false_type{});
 
   if (want_stats) {
     __syncthreads();
@@ -2036,19 +2159,41 @@ extern "C" int coclr_conv3d_ntiles(const coclr_conv_desc* d, int* ntiles) {
   return 0;
 }
 
+extern "C" int coclr_conv3d_bwd_sums_ok(const coclr_conv_desc* d, int* ok) {
+  ConvPlan p;
+  int v;
+  int rc = plan_forward(d, &p, &v);
+  if (rc) return rc;
+  *ok = (v != 60 && v != 31) ? 1 : 0;
+  return 0;
+}
+
 namespace {
+
+inline bool bwd_sums_variant(int variant) { return variant != 60 && variant != 31; }
 
 // The launch behind coclr_conv3d_fwd.  With `slot`, variants that have a pair kernel fill it instead of
 // launching (see PairSlot).
 int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_packed, float* y,
                     float* stats, const float* bias, const float* ep_scale, const float* ep_shift,
                     const int64_t* n_index, int relu, int accumulate, hipStream_t stream,
-                    PairSlot* slot) {
+                    PairSlot* slot, const coclr_conv_call* bw = nullptr) {
   ConvPlan p;
   int variant;
   int rc = plan_forward(d, &p, &variant);
   if (rc) return rc;
   ConvArgs a;
+  a.bwd_y = nullptr; a.bwd_scale = a.bwd_shift = a.bwd_mean = a.bwd_invstd = nullptr; a.bwd_relu = 0;
+  if (bw && bw->bwd_y) {
+    // backward sums of the BatchNorm unit whose dz this data gradient writes: only in the kernels whose
+    // epilogue forms them (not the spatial Winograd / stem kernels), into the statistics slots, and never
+    // together with an epilogue of the forward kind
+    if (!bwd_sums_variant(variant) || !stats || accumulate || bias || ep_scale || relu || n_index ||
+        !bw->bwd_scale || !bw->bwd_shift || !bw->bwd_mean || !bw->bwd_invstd)
+      return COCLR_EINVAL;
+    a.bwd_y = bw->bwd_y; a.bwd_scale = bw->bwd_scale; a.bwd_shift = bw->bwd_shift;
+    a.bwd_mean = bw->bwd_mean; a.bwd_invstd = bw->bwd_invstd; a.bwd_relu = bw->bwd_relu;
+  }
   a.x = x; a.w = w_packed; a.y = y; a.stats = stats; a.bias = bias;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.n_index = n_index;
   a.x_nstride = d->x_nstride; a.y_nstride = d->y_nstride;
@@ -2218,7 +2363,7 @@ extern "C" int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void*
       for (int j = i; j < n && j < i + 2; ++j) {
         const coclr_conv_call& c = calls[j];
         int rc = conv3d_fwd_impl(c.d, c.x, c.w_packed, c.y, c.stats, c.bias, c.ep_scale, c.ep_shift,
-                                 c.n_index, c.relu, c.accumulate, stream, nullptr);
+                                 c.n_index, c.relu, c.accumulate, stream, nullptr, &c);
         if (rc) return rc;
       }
       continue;
@@ -2229,10 +2374,10 @@ extern "C" int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void*
     s0.pair = s1.pair = nullptr;
     s0.single = s1.single = nullptr;
     int rc = conv3d_fwd_impl(c0.d, c0.x, c0.w_packed, c0.y, c0.stats, c0.bias, c0.ep_scale, c0.ep_shift,
-                             c0.n_index, c0.relu, c0.accumulate, stream, &s0);
+                             c0.n_index, c0.relu, c0.accumulate, stream, &s0, &c0);
     if (rc) return rc;
     rc = conv3d_fwd_impl(c1.d, c1.x, c1.w_packed, c1.y, c1.stats, c1.bias, c1.ep_scale, c1.ep_shift,
-                         c1.n_index, c1.relu, c1.accumulate, stream, &s1);
+                         c1.n_index, c1.relu, c1.accumulate, stream, &s1, &c1);
     if (rc) return rc;
     PairFn fused = nullptr;
     if (s0.pending && s1.pending) fused = s0.single == s1.single ? s0.pair : mixed_pair(s0.single, s1.single);

@@ -91,9 +91,15 @@ _LANES = {}
 # critical stream).  Self-healing: a stale slot (buckets rebuilt, wrapper re-created) is just memory
 # -- DDP's own alias check copies from it as from any other gradient -- and the hook refreshes it.
 _GRAD_SLOTS = {}      # id(param) -> (weakref(param), bucket view)
+# Slots the hook has SEEN DDP accept: a whole backward pass after which the bucket still lived at the
+# published address and every gradient in it was an alias of its view.  Only then is it known that DDP
+# launches nothing on the main stream that reads the gradient (its per-parameter copy out of a stale view
+# after the one bucket rebuild does), which is what an un-joined weight-gradient stream needs (defer_side).
+_SLOTS_VERIFIED = set()
 
 
 def set_grad_slot(param, view):
+    _SLOTS_VERIFIED.discard(id(param))
     if view is None:
         _GRAD_SLOTS.pop(id(param), None)
         return
@@ -267,6 +273,10 @@ class Run:
         # whose grad_fn owns that stage's run) -- GBs of activations parked behind gc's schedule.
         self.tape = []
         self.pooled = {}       # id(unit output) -> (pool geom, d(pool output), arg-max): see max_pool
+        # BatchNorm backward sums formed by the data gradient that writes the unit's dz (FUSE_BN_REDUCE):
+        self.bn_src = {}       # id(unit output) -> (y, scale, shift, mean, invstd, relu) of a training unit
+        self.bn_parts = {}     # id(unit output) -> [(partial sums, slots per channel)] left by that writer
+        self.grad_writes = {}  # id(activation) -> writers of its gradient so far (grad_target)
         self.cur_lane = None
         self.lanes_on = False  # set per inception block (lanes_for)
         self._in_lane = False
@@ -306,6 +316,7 @@ class Run:
         """(tensor to write d(val) into, accumulate?)"""
         if not val.whole:
             raise RuntimeError("coclr_amd: gradient into a channel slice is not supported")
+        self.grad_writes[id(val.base)] = self.grad_writes.get(id(val.base), 0) + 1
         g = self.grads.get(id(val.base))
         if g is None:
             g = torch.empty_like(val.base)
@@ -392,7 +403,7 @@ class Run:
             for st in started.values():
                 cur.wait_stream(st)
         if defer_join and self._side_used and self.param_grads and \
-                all(k in self._slots_out for k in self.param_grads):
+                all(k in self._slots_out and k in _SLOTS_VERIFIED for k in self.param_grads):
             self.defer_side()
         else:
             self.join_side()
@@ -446,8 +457,10 @@ class Run:
         With the backbone as one node per stage (world > 1) every node used to end with a join: the next
         stage's data-gradient chain then waited for this stage's weight gradients.  Nothing on the main
         stream needs them: when EVERY parameter gradient of the node was written into DistributedDataParallel's
-        bucket views (grad_out), autograd only adopts aliases (no kernel reads them) and the bucket hook
-        (coclr_amd/parallel.py) makes the all-reduce wait for the weight-gradient stream itself.  The last
+        bucket views (grad_out) and those views are known to be DDP's current ones (_SLOTS_VERIFIED: out of a
+        stale view DDP would copy on the main stream), autograd only adopts aliases (no kernel reads them)
+        and the bucket hook (coclr_amd/parallel.py) makes the all-reduce wait for the weight-gradient stream
+        itself.  The last
         node of the backward pass (stage 1) joins as before, which also orders everything in front of the
         optimiser.  What the side kernels read stays referenced until then."""
         DEFERRED[0] += 1
@@ -590,8 +603,12 @@ def _exec(req):
         if c.get("want_stats"):
             nt = c["geom"].ntiles()
             stats = torch.empty(2 * c["geom"].Cout * nt, dtype=torch.float32, device=c["y"].device)
-        ops.conv_fwd(c["geom"], c["x"], c["w"], c["y"], stats=stats, n_index=c.get("n_index"),
-                     accumulate=c.get("accumulate", False))
+        if c.get("bwd_bn") is not None:
+            c["stats"] = stats
+            ops.conv_fwd_multi([c])
+        else:
+            ops.conv_fwd(c["geom"], c["x"], c["w"], c["y"], stats=stats, n_index=c.get("n_index"),
+                         accumulate=c.get("accumulate", False))
         return stats, nt
     if kind == "bn_fwd":           # c: list of units
         if len(c) > 1:
@@ -609,6 +626,9 @@ def _exec(req):
             ops.bn_act_backward_multi(c)
             return None
         u = c[0]
+        if u.get("partials"):
+            ops.bn_act_backward_multi(c)
+            return None
         ops.bn_act_backward(u["dz"], u["y"], None, u["scale"], u["shift"], u["mean"], u["invstd"], u["sums"],
                             u["dy"], None, u["dgamma"], u["dbeta"], u["relu"], u["training"])
         return None
@@ -812,6 +832,10 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
         x_needs = run.needs_grad(x)
         if n_index is not None and x_needs:
             raise NotImplementedError("coclr_amd: gathered conv input cannot require grad")
+        if FUSE_BN_REDUCE and training and residual is None and out.whole and \
+                N * odim[0] * odim[1] * odim[2] > ops.SMALL_CHANNEL:
+            # whoever writes d(out) alone and in one piece may form this unit's backward sums on the way
+            run.bn_src[id(out.base)] = (y, scale, shift, mean, invstd, relu)
 
         def backward(run):
             dy = torch.empty_like(y)
@@ -824,9 +848,12 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
                 ops.bn_act_backward_pooled(pooled[0], pooled[1], pooled[2], y, scale, shift, mean,
                                            invstd, sums, dy, dgb[0], dgb[1], relu, training)
             elif residual is None:
+                parts = run.bn_parts.pop(id(out.base), None)
+                if parts is not None and run.grad_writes.get(id(out.base), 0) != 1:
+                    parts = None          # somebody else wrote d(out) too: the sums are stale
                 yield ("bn_bwd", [dict(dz=run.grad_of(out), y=y, scale=scale, shift=shift, mean=mean,
                                        invstd=invstd, sums=sums, dy=dy, dgamma=dgb[0], dbeta=dgb[1], relu=relu,
-                                       training=training)])
+                                       training=training, partials=parts)])
             else:
                 dz = run.grad_of(out)
                 dres = None
@@ -852,15 +879,31 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
                 if sliced:
                     raise NotImplementedError("coclr_amd: dgrad of the sliced stem conv")
                 dx, acc = run.grad_target(x)
+                # dx is the dz of the unit that produced x: when this launch is its first writer (and, checked
+                # by that unit, its only one) the kernel forms that unit's BatchNorm backward sums as well
+                src = run.bn_src.get(id(x.base)) if (not acc and x.whole) else None
                 phases = geoms[0].dgrad_phases()
                 if phases is not None:
                     # strided conv: one dense stride-1 correlation per residue class of dX
+                    if src is not None and not (len(phases) <= 2 and all(ph[0].bwd_sums_ok() for ph in phases)):
+                        src = None
                     for pg, k0, nk, step in phases:
-                        ops.conv_fwd(pg, dy, run.pack(w, True, taps=nk, tap_base=k0,
-                                                      tap_step=step), dx, accumulate=acc)
+                        wp = run.pack(w, True, taps=nk, tap_base=k0, tap_step=step)
+                        if src is not None:
+                            nt = pg.ntiles()
+                            st = torch.empty(2 * pg.Cout * nt, dtype=torch.float32, device=dx.device)
+                            ops.conv_fwd_multi([dict(geom=pg, x=dy, w=wp, y=dx, stats=st, bwd_bn=src)])
+                            run.bn_parts.setdefault(id(x.base), []).append((st, nt))
+                        else:
+                            ops.conv_fwd(pg, dy, wp, dx, accumulate=acc)
                 else:
                     dg = geoms[0].dgrad()
-                    yield ("conv", dict(geom=dg, x=dy, w=run.pack(w, True, algo=dg.algo), y=dx, accumulate=acc))
+                    if src is not None and not dg.bwd_sums_ok():
+                        src = None
+                    res = yield ("conv", dict(geom=dg, x=dy, w=run.pack(w, True, algo=dg.algo), y=dx,
+                                              accumulate=acc, want_stats=src is not None, bwd_bn=src))
+                    if src is not None:
+                        run.bn_parts.setdefault(id(x.base), []).append(res)
 
         run.record(backward)
     elif y is not None:
@@ -869,6 +912,12 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
 
 
 LAZY_APPLY = os.environ.get("COCLR_LAZY_APPLY", "1") != "0"
+# BatchNorm backward sums in the epilogue of the data gradient that writes the unit's dz (single writer):
+# one read of y there instead of the reduction pass over dz and y.  OPT-IN: measured on an MI355X at B=32
+# (tools/r04_flaky.sh, four alternating pairs) it is worth nothing -- 1030.9 vs 1031.1 clips/s -- because
+# the HBM-bound reduction passes it removes ran under the MFMA-bound weight gradients of the other stream,
+# while the extra loads lengthen MFMA-bound kernels on the critical one.
+FUSE_BN_REDUCE = os.environ.get("COCLR_FUSE_BN_REDUCE", "0") != "0"
 POOLED_BACKWARD = os.environ.get("COCLR_POOLED_BACKWARD", "1") != "0"
 FUSE_POINTWISE = True     # debugging switch: False runs the units of a group one by one
 

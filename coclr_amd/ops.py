@@ -202,6 +202,16 @@ class ConvGeom:
             v = self._cache["ntiles"] = out.value
         return v
 
+    def bwd_sums_ok(self):
+        """Can this problem's kernel form BatchNorm backward sums in its epilogue (conv_fwd_multi bwd_bn)?"""
+        v = self._cache.get("bwd_sums_ok")
+        if v is None:
+            out = C.c_int32(0)
+            _lib.check(_L().coclr_conv3d_bwd_sums_ok(C.byref(self.desc), C.byref(out)),
+                       "conv3d_bwd_sums_ok", self)
+            v = self._cache["bwd_sums_ok"] = bool(out.value)
+        return v
+
     def wgrad_workspace(self):
         v = self._cache.get("wgws")
         if v is None:
@@ -318,8 +328,10 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
 
 def conv_fwd_multi(calls):
     """Independent convolutions in one call (consecutive pairs of the same kernel variant in one launch).
-    calls: [dict(geom, x, w, y, stats=None, n_index=None, accumulate=False)]; every problem keeps the plan it
-    has alone (statistics: geom.ntiles() slots per channel)."""
+    calls: [dict(geom, x, w, y, stats=None, n_index=None, accumulate=False, bwd_bn=None)]; every problem keeps
+    the plan it has alone (statistics: geom.ntiles() slots per channel).  bwd_bn = (y, scale, shift, mean,
+    invstd, relu) of a BatchNorm unit: the problem is the data gradient that writes that unit's dz and `stats`
+    receives the unit's backward sums (include/coclr_hip.h, coclr_conv_call)."""
     n = len(calls)
     arr = (ConvCall * n)()
     descs = []
@@ -339,6 +351,14 @@ def conv_fwd_multi(calls):
         a.n_index = _p(c.get("n_index"), torch.int64)
         a.relu = 0
         a.accumulate = int(bool(c.get("accumulate", False)))
+        bb = c.get("bwd_bn")
+        if bb is not None:
+            # (y, scale, shift, mean, invstd, relu) of the BatchNorm unit whose dz this data gradient writes
+            by = bb[0]
+            if by.shape != y.shape or _chk5(by, "bwd_y") != d.y_nstride or not y.is_contiguous():
+                raise ValueError("coclr_amd: bwd_bn's conv output must be laid out like the destination")
+            a.bwd_y, a.bwd_scale, a.bwd_shift = _p(by), _p(bb[1]), _p(bb[2])
+            a.bwd_mean, a.bwd_invstd, a.bwd_relu = _p(bb[3]), _p(bb[4]), int(bool(bb[5]))
     _lib.check(_L().coclr_conv3d_fwd_multi(arr, n, _stream()), "conv3d_fwd_multi",
                [c["geom"] for c in calls])
 
@@ -424,7 +444,8 @@ def bn_finalize_apply_multi(units):
 
 def bn_act_backward_multi(units):
     """bn_act_backward (no residual) for several units in one call.
-    units: [dict(dz, y, scale, shift, mean, invstd, sums, dy, dgamma, dbeta, relu, training)]."""
+    units: [dict(dz, y, scale, shift, mean, invstd, sums, dy, dgamma, dbeta, relu, training, partials=None)];
+    partials = [(stats, ntiles)] formed by the data gradient that wrote dz (conv_fwd_multi bwd_bn)."""
     n = len(units)
     arr = (BnBwdCall * n)()
     for a, u in zip(arr, units):
@@ -439,6 +460,16 @@ def bn_act_backward_multi(units):
         a.S = T * H * W
         a.dz_nstride, a.y_nstride, a.dy_nstride = _chk5(u["dz"], "dz"), _chk5(y, "y"), _chk5(u["dy"], "dy")
         a.N, a.C, a.relu, a.training = N, C_, int(u["relu"]), int(u["training"])
+        parts = u.get("partials")
+        if parts:
+            # [(stats, ntiles)] left by the data gradient(s) that wrote dz: no reduction pass
+            if len(parts) > 2:
+                raise ValueError("coclr_amd: at most two partial-sum arrays per BatchNorm backward")
+            for i, (st, nt) in enumerate(parts):
+                if st.numel() != 2 * C_ * nt:
+                    raise ValueError("coclr_amd: partial sums do not match the unit's channels")
+                a.part[i] = _p(st)
+                a.part_ntiles[i] = nt
     _lib.check(_L().coclr_bn_act_backward_multi(arr, n, _stream()), "bn_act_backward_multi")
 
 

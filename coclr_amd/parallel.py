@@ -82,6 +82,7 @@ class _HookState:
         self.group = group
         self.seen = {}        # bucket index -> (buffer address, #parameters) already published
         self.published = {}   # id(param) -> weakref(param): slots this wrapper handed to the engine
+        self.verified = set() # bucket indices whose published views DDP has been seen to accept
 
 
 def _drop_slots(published):
@@ -128,6 +129,15 @@ def bucket_hook(state, bucket):
             engine.set_grad_slot(p, g)
             state.published[id(p)] = weakref.ref(p)
         state.seen[idx] = sig
+        state.verified.discard(idx)
+    elif idx not in state.verified:
+        # same bucket memory as last time: if every gradient DDP holds for it IS the view the engine was
+        # given, DDP copied nothing this pass and will not next time either (engine._SLOTS_VERIFIED)
+        params = bucket.parameters()
+        if all(p.grad is not None and p.grad.data_ptr() == g.data_ptr()
+               for p, g in zip(params, bucket.gradients())):
+            engine._SLOTS_VERIFIED.update(id(p) for p in params)
+            state.verified.add(idx)
     group = state.group if state.group is not None else dist.group.WORLD
     world = dist.get_world_size(group)
     if world == 1:

@@ -129,8 +129,24 @@ typedef struct coclr_conv_call {
   const float* ep_shift;
   const int64_t* n_index;
   int32_t relu, accumulate;
+  /* Data gradient whose destination y is the dz of a BatchNorm(+ReLU) unit (the producer of the tensor
+   * this convolution read in forward): bwd_y = that unit's convolution output, laid out exactly like y,
+   * bwd_scale / bwd_shift / bwd_mean / bwd_invstd its per-channel coefficients.  The kernel then also
+   * forms the unit's backward sums while dz is in registers -- g = dz where bwd_relu == 0 or
+   * bwd_y*scale + shift > 0; stats[0][c][tile] = sum g, stats[1][c][tile] = sum g*(bwd_y - mean)*invstd --
+   * and coclr_bn_act_backward_multi takes them as `part` instead of running its reduction pass over dz
+   * and y (aten::native_batch_norm_backward's sums + threshold_backward; backbone/s3dg.py:46-48,60-64).
+   * Requires stats, no accumulate / bias / ep_* / relu / n_index, and a kernel that has the epilogue
+   * (coclr_conv3d_bwd_sums_ok; COCLR_EINVAL otherwise).  All NULL / 0: a plain call. */
+  const float* bwd_y;
+  const float* bwd_scale;
+  const float* bwd_shift;
+  const float* bwd_mean;
+  const float* bwd_invstd;
+  int32_t bwd_relu, reserved;
 } coclr_conv_call;
 int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void* stream);
+int coclr_conv3d_bwd_sums_ok(const coclr_conv_desc* d, int* ok);
 
 /* Split-K workspace (fp32 elements) for coclr_conv3d_wgrad. */
 int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* elems);
@@ -248,6 +264,11 @@ typedef struct coclr_bn_bwd_call {
   double* sums_ws; float* dy; float* dgamma; float* dbeta;
   int64_t S, dz_nstride, y_nstride, dy_nstride;
   int32_t N, C, relu, training;
+  /* Backward sums already formed by the data gradient(s) that wrote dz (coclr_conv_call.bwd_y): up to two
+   * [2][C][part_ntiles[i]] arrays (a strided convolution's data gradient is one launch per residue class).
+   * part[0] != NULL: the reduction pass is replaced by a fold of these partials (fp64, fixed order). */
+  const float* part[2];
+  int32_t part_ntiles[2];
 } coclr_bn_bwd_call;
 int coclr_bn_finalize_apply_multi(const coclr_bn_fwd_call* calls, int n, void* stream);
 int coclr_bn_act_backward_multi(const coclr_bn_bwd_call* calls, int n, void* stream);

@@ -129,8 +129,27 @@ def conv_fwd(geom, x, w_packed, y, stats=None, bias=None, ep_scale=None, ep_shif
 def conv_fwd_multi(calls):
     """The pair / multi entry point: every problem on its own."""
     for c in calls:
-        conv_fwd(c["geom"], c["x"], c["w"], c["y"], stats=c.get("stats"), n_index=c.get("n_index"),
-                 accumulate=c.get("accumulate", False))
+        bb = c.get("bwd_bn")
+        conv_fwd(c["geom"], c["x"], c["w"], c["y"], stats=None if bb is not None else c.get("stats"),
+                 n_index=c.get("n_index"), accumulate=c.get("accumulate", False))
+        if bb is not None:
+            # the data gradient that writes a BatchNorm unit's dz also forms that unit's backward sums
+            geom, y = c["geom"], c["y"]
+            assert not c.get("accumulate", False) and c.get("stats") is not None and geom.bwd_sums_ok()
+            by, scale, shift, mean, invstd, relu = bb
+            assert by.shape == y.shape
+            sel = (slice(None),) * 5
+            if getattr(geom, "lattice", None) is not None:
+                ys, yo, _ = geom.lattice
+                sel = (slice(None), slice(None), slice(yo[0], None, ys[0]), slice(yo[1], None, ys[1]),
+                       slice(yo[2], None, ys[2]))
+            g, u = y[sel], by[sel]
+            if relu:
+                g = g * ((u * _b(scale) + _b(shift)) > 0)
+            st = c["stats"].view(2, geom.Cout, geom.ntiles())
+            st.zero_()
+            st[0, :, 0] = g.sum((0, 2, 3, 4))
+            st[1, :, 0] = (g * ((u - _b(mean)) * _b(invstd))).sum((0, 2, 3, 4))
 
 
 def bn_finalize_apply_multi(units):
@@ -144,8 +163,15 @@ def bn_finalize_apply_multi(units):
 
 def bn_act_backward_multi(units):
     for u in units:
+        sums = None
+        if u.get("partials"):
+            # the reduction was done by the data gradient(s) that wrote dz: fold their partials
+            C_ = u["y"].shape[1]
+            sg = sum(st.view(2, C_, nt)[0].double().sum(1) for st, nt in u["partials"])
+            sgx = sum(st.view(2, C_, nt)[1].double().sum(1) for st, nt in u["partials"])
+            sums = (sg, sgx)
         bn_act_backward(u["dz"], u["y"], None, u["scale"], u["shift"], u["mean"], u["invstd"], u["sums"],
-                        u["dy"], None, u["dgamma"], u["dbeta"], u["relu"], u["training"])
+                        u["dy"], None, u["dgamma"], u["dbeta"], u["relu"], u["training"], _sums=sums)
 
 
 def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accumulate=False):
@@ -218,14 +244,17 @@ def bn_backward_workspace(N, C_):
 
 
 def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dgamma,
-                    dbeta, relu, training, dres_accumulate=False):
+                    dbeta, relu, training, dres_accumulate=False, _sums=None):
     g = dz
     if relu:
         mask = (z > 0) if z is not None else ((y * _b(scale) + _b(shift)) > 0)
         g = dz * mask
     xhat = (y - _b(mean)) * _b(invstd)
-    sg = g.double().sum((0, 2, 3, 4))
-    sgx = (g.double() * xhat.double()).sum((0, 2, 3, 4))
+    if _sums is not None:
+        sg, sgx = _sums
+    else:
+        sg = g.double().sum((0, 2, 3, 4))
+        sgx = (g.double() * xhat.double()).sum((0, 2, 3, 4))
     if dgamma is not None:
         dgamma.copy_(sgx.float())
     if dbeta is not None:

@@ -1,4 +1,4 @@
-"""Multi-problem launches (ABI 15): coclr_conv3d_fwd_multi, coclr_bn_finalize_apply_multi,
+"""Multi-problem launches (ABI 15, sums epilogue: 16): coclr_conv3d_fwd_multi, coclr_bn_finalize_apply_multi,
 coclr_bn_act_backward_multi and the engine's lockstep emission of the two separable branches of an
 inception block (backbone/s3dg.py:100-118).  Every problem keeps the plan it has alone, so the bar is
 BIT-IDENTITY with the single launches: outputs, BatchNorm statistics, running buffers, gradients."""
@@ -217,3 +217,197 @@ def test_paired_inception_block_matches_unpaired(block, dims, monkeypatch):
             assert torch.equal(ref[2][k], other[2][k]), k
         for k in ref[3]:
             assert torch.equal(ref[3][k], other[3][k]), k
+
+
+# ---- BatchNorm backward sums formed by the data gradient that writes dz (ABI 16) -------------------------
+
+def _bwd_bn_operands(shape, seed, relu=True):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    C_ = shape[1]
+    by = torch.randn(*shape, device="cuda", generator=g)
+    scale = torch.randn(C_, device="cuda", generator=g)
+    shift = torch.randn(C_, device="cuda", generator=g) * 0.3
+    mean = torch.randn(C_, device="cuda", generator=g) * 0.2
+    invstd = torch.rand(C_, device="cuda", generator=g) + 0.5
+    return (by, scale, shift, mean, invstd, relu)
+
+
+def _reference_sums(dz, bb):
+    by, scale, shift, mean, invstd, relu = bb
+    b = lambda v: v.view(1, -1, 1, 1, 1)
+    g = dz.double()
+    if relu:
+        g = g * (torch.addcmul(b(shift), by, b(scale)) > 0)     # the kernels' fmaf
+    xhat = ((by - b(mean)) * b(invstd)).double()
+    return g.sum((0, 2, 3, 4)), (g * xhat).sum((0, 2, 3, 4))
+
+
+SUMS = [
+    # the temporal half of a separable unit: F(2,3) data gradient -> the unit's bn1 (Conv_2c, Mixed_3b/3c sizes)
+    ("2c conv2", (192, 192, (3, 1, 1), (1, 0, 0), (16, 32, 32))),
+    ("3c b1 conv2", (192, 192, (3, 1, 1), (1, 0, 0), (16, 16, 16))),
+    ("3b b2 conv2", (32, 32, (3, 1, 1), (1, 0, 0), (16, 16, 16))),
+    ("odd frames", (48, 40, (3, 1, 1), (1, 0, 0), (7, 8, 8))),
+    # direct kernels: small-map (1,3,3) and pointwise
+    ("4b b1 conv1", (96, 208, (1, 3, 3), (0, 1, 1), (8, 8, 8))),
+    ("4b heads", (480, 304, (1, 1, 1), (0, 0, 0), (8, 8, 8))),
+]
+
+
+@pytest.mark.parametrize("name,spec", SUMS, ids=[s[0] for s in SUMS])
+@pytest.mark.parametrize("relu", [True, False])
+def test_data_gradient_forms_batchnorm_backward_sums(name, spec, relu):
+    """coclr_conv_call.bwd_y: dz is bit-identical to the plain data gradient, the folded partial sums are
+    the float64 sums over the whole tensor (1e-5 of the sum of magnitudes: fp32 partials per tile), and
+    coclr_bn_act_backward_multi on those partials gives the dy / dgamma / dbeta of its own reduction."""
+    from coclr_amd import engine, ops
+    run = engine.Run(torch.device("cuda"), save=False)
+    case = _conv_case(run, *spec, seed=31, dgrad=True)
+    geom = case["geom"]
+    assert geom.bwd_sums_ok()
+    plain, _ = _run_single(case)
+    bb = _bwd_bn_operands(tuple(plain.shape), 32, relu)
+    dz = case["y0"].clone()
+    nt = geom.ntiles()
+    st = torch.full((2 * geom.Cout * nt,), 7.0, device="cuda")
+    ops.conv_fwd_multi([dict(geom=geom, x=case["x"], w=case["w"], y=dz, stats=st, bwd_bn=bb)])
+    torch.cuda.synchronize()
+    assert torch.equal(dz, plain)
+    sg, sgx = _reference_sums(dz, bb)
+    got = st.view(2, geom.Cout, nt).double().sum(2)
+    mag_g, mag_gx = _reference_sums(dz.abs(), (bb[0], bb[1], bb[2], bb[3], bb[4], relu))
+    assert ((got[0] - sg).abs() <= 1e-5 * mag_g + 1e-6).all()
+    by, scale, shift, mean, invstd, _ = bb
+    xabs = ((by - mean.view(1, -1, 1, 1, 1)) * invstd.view(1, -1, 1, 1, 1)).abs().double()
+    gabs = dz.abs().double()
+    assert ((got[1] - sgx).abs() <= 1e-5 * (gabs * xabs).sum((0, 2, 3, 4)) + 1e-6).all()
+
+    # the unit's backward from those partials against its own reduction pass
+    N, C_ = dz.shape[0], dz.shape[1]
+    outs = []
+    for parts in (None, [(st, nt)]):
+        dy = torch.empty_like(dz)
+        dgamma, dbeta = torch.empty(C_, device="cuda"), torch.empty(C_, device="cuda")
+        sums = torch.empty(ops.bn_backward_workspace(N, C_), dtype=torch.float64, device="cuda")
+        ops.bn_act_backward_multi([dict(dz=dz, y=by, scale=scale, shift=shift, mean=mean, invstd=invstd,
+                                        sums=sums, dy=dy, dgamma=dgamma, dbeta=dbeta, relu=relu, training=True,
+                                        partials=parts)])
+        outs.append((dy, dgamma, dbeta))
+    torch.cuda.synchronize()
+    for a, b_ in zip(*outs):
+        assert (a - b_).abs().max() <= 2e-5 * b_.abs().max() + 1e-6
+
+
+def test_strided_phases_form_the_sums_together():
+    """Conv_1a.conv2 is (7,1,1) stride 2: its data gradient is one launch per residue class of dX
+    (ConvGeom.dgrad_phases), each with its own partial sums; the fold takes both."""
+    from coclr_amd import engine, ops
+    run = engine.Run(torch.device("cuda"), save=False)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N, Cc, idim = 8, 64, (16, 32, 32)
+    geom = ops.conv_geom(N, Cc, Cc, idim, (7, 1, 1), (2, 1, 1), (3, 0, 0))
+    w = torch.randn(Cc, Cc, 7, 1, 1, device="cuda", generator=g) * 0.05
+    dyo = torch.randn(N, Cc, *geom.odim, device="cuda", generator=g)
+    phases = geom.dgrad_phases()
+    assert phases is not None and len(phases) == 2 and all(ph[0].bwd_sums_ok() for ph in phases)
+    plain = torch.zeros(N, Cc, *idim, device="cuda")
+    dz = torch.zeros_like(plain)
+    bb = _bwd_bn_operands(tuple(dz.shape), 4)
+    parts = []
+    for pg, k0, nk, step in phases:
+        wp = run.pack(w, True, taps=nk, tap_base=k0, tap_step=step)
+        ops.conv_fwd(pg, dyo, wp, plain)
+        nt = pg.ntiles()
+        st = torch.empty(2 * Cc * nt, device="cuda")
+        ops.conv_fwd_multi([dict(geom=pg, x=dyo, w=wp, y=dz, stats=st, bwd_bn=bb)])
+        parts.append((st, nt))
+    torch.cuda.synchronize()
+    assert torch.equal(dz, plain)
+    sg, sgx = _reference_sums(dz, bb)
+    got = sum(st.view(2, Cc, nt).double().sum(2) for st, nt in parts)
+    assert ((got[0] - sg).abs() <= 1e-5 * dz.abs().double().sum((0, 2, 3, 4))).all()
+    outs = []
+    for pp in (None, parts):
+        dy = torch.empty_like(dz)
+        dgamma, dbeta = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+        sums = torch.empty(ops.bn_backward_workspace(N, Cc), dtype=torch.float64, device="cuda")
+        ops.bn_act_backward_multi([dict(dz=dz, y=bb[0], scale=bb[1], shift=bb[2], mean=bb[3], invstd=bb[4],
+                                        sums=sums, dy=dy, dgamma=dgamma, dbeta=dbeta, relu=True, training=True,
+                                        partials=pp)])
+        outs.append((dy, dgamma, dbeta))
+    torch.cuda.synchronize()
+    for a, b_ in zip(*outs):
+        assert (a - b_).abs().max() <= 2e-5 * b_.abs().max() + 1e-6
+
+
+def test_backward_sums_in_pair_launches_and_refusals():
+    """Two temporal data gradients in one launch, each with its own unit's sums; the spatial Winograd kernel
+    has no such epilogue and says so (bwd_sums_ok False, COCLR_EINVAL when asked anyway), and the
+    combination with an accumulating destination is refused."""
+    from coclr_amd import engine, ops, _lib
+    run = engine.Run(torch.device("cuda"), save=False)
+    cases = [_conv_case(run, *spec, seed=41 + i, dgrad=True)
+             for i, spec in enumerate([(208, 208, (3, 1, 1), (1, 0, 0), (8, 8, 8)),
+                                       (48, 48, (3, 1, 1), (1, 0, 0), (8, 8, 8))])]
+    singles, pairs = [], []
+    for c in cases:
+        bb = _bwd_bn_operands(tuple(c["y0"].shape), 50 + c["geom"].Cout)
+        c["bb"] = bb
+        nt = c["geom"].ntiles()
+        dz, st = c["y0"].clone(), torch.empty(2 * c["geom"].Cout * nt, device="cuda")
+        ops.conv_fwd_multi([dict(geom=c["geom"], x=c["x"], w=c["w"], y=dz, stats=st, bwd_bn=bb)])
+        singles.append((dz, st))
+    ys = [c["y0"].clone() for c in cases]
+    sts = [torch.empty_like(s[1]) for s in singles]
+    ops.conv_fwd_multi([dict(geom=c["geom"], x=c["x"], w=c["w"], y=y, stats=st, bwd_bn=c["bb"])
+                        for c, y, st in zip(cases, ys, sts)])
+    torch.cuda.synchronize()
+    for (dz, st), y, s2 in zip(singles, ys, sts):
+        assert torch.equal(dz, y) and torch.equal(st, s2)
+
+    wide = _conv_case(run, 64, 192, (1, 3, 3), (0, 1, 1), (16, 32, 32), seed=60, dgrad=True)
+    if wide["geom"].algo == 1:
+        assert not wide["geom"].bwd_sums_ok()
+        bb = _bwd_bn_operands(tuple(wide["y0"].shape), 61)
+        st = torch.empty(2 * wide["geom"].Cout * wide["geom"].ntiles(), device="cuda")
+        with pytest.raises(_lib.HipLibraryError):
+            ops.conv_fwd_multi([dict(geom=wide["geom"], x=wide["x"], w=wide["w"], y=wide["y0"].clone(),
+                                     stats=st, bwd_bn=bb)])
+    c = cases[0]
+    with pytest.raises(_lib.HipLibraryError):
+        ops.conv_fwd_multi([dict(geom=c["geom"], x=c["x"], w=c["w"], y=c["y0"].clone(), stats=sts[0],
+                                 bwd_bn=c["bb"], accumulate=True)])
+
+
+def test_engine_with_the_sums_epilogue_matches_the_reduction_pass(monkeypatch):
+    """COCLR_FUSE_BN_REDUCE=1 (opt-in): the S3D backbone's backward with Conv_1a.bn1 / Conv_2c.bn1 taking their
+    sums from the data gradients' epilogues against the default reduction passes -- same forward, same ReLU
+    masks, sums folded from fp32 tile partials instead of per-sample fp64 partials: every parameter gradient
+    within 1e-5 of the tensor's largest entry."""
+    from coclr_amd import engine, ops
+    from coclr_amd.backbone import s3dg
+    used = {"n": 0}
+    real = ops.bn_act_backward_multi
+
+    def spy(units):
+        used["n"] += sum(1 for u in units if u.get("partials"))
+        return real(units)
+
+    monkeypatch.setattr(ops, "bn_act_backward_multi", spy)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(16, 3, 16, 64, 64, device="cuda", generator=g)
+    grads = []
+    for fuse in (False, True):
+        monkeypatch.setattr(engine, "FUSE_BN_REDUCE", fuse)
+        torch.manual_seed(0)
+        m = s3dg.S3D(input_channel=3).cuda().train()
+        used["n"] = 0
+        out = m(x)
+        out.square().mean().backward()
+        torch.cuda.synchronize()
+        grads.append(({k: p.grad.clone() for k, p in m.named_parameters()}, out.detach().clone(), used["n"]))
+    (ga, oa, na), (gb, ob, nb) = grads
+    assert na == 0 and nb >= 2, (na, nb)
+    assert torch.equal(oa, ob)
+    for k in ga:
+        assert (ga[k] - gb[k]).abs().max() <= 1e-5 * ga[k].abs().max() + 1e-12, k

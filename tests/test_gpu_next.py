@@ -384,7 +384,7 @@ def test_gradients_in_ddp_buckets_bit_identical_and_deterministic(monkeypatch):
 
     from coclr_amd.backbone import s3dg
 
-    def run(hook, split=False):
+    def run(hook, split=False, steps=4):
         monkeypatch.setenv("COCLR_DDP_HOOK", "1" if hook else "0")
         monkeypatch.setattr(s3dg, "_SPLIT_MODE", "1" if split else "0")
         engine._GRAD_SLOTS.clear()
@@ -395,7 +395,7 @@ def test_gradients_in_ddp_buckets_bit_identical_and_deterministic(monkeypatch):
                                weight_decay=1e-5)
         ddp.train()
         aliased = []
-        for step in range(4):
+        for step in range(steps):
             g = torch.Generator().manual_seed(50 + step)
             block = torch.randn(4, 2, 3, 16, 64, 64, generator=g).cuda()
             torch.manual_seed(60 + step)
@@ -426,11 +426,15 @@ def test_gradients_in_ddp_buckets_bit_identical_and_deterministic(monkeypatch):
         # one autograd node per backbone stage (the structure at world > 1): stages 5..2 leave the
         # weight-gradient stream un-joined once their gradients live in the buckets (engine.Run.defer_side);
         # the result does not move by a bit
+        # (from the step after the hook has seen DDP accept the views: step 2 writes into views of the
+        # buckets DDP has just rebuilt away, and DDP copies out of them on the main stream)
         before = engine.DEFERRED[0]
-        got2, aliased2, _ = run(True, split=True)
+        ref6, _, _ = run(False, steps=6)
+        got2, aliased2, _ = run(True, split=True, steps=6)
         assert aliased2[-1] == nparams
-        assert engine.DEFERRED[0] - before >= 4 * 2, "stages 2-5 should have deferred in steps 3 and 4"
-        for a, b in zip(ref, got2):
+        if engine.DEFER_JOIN:
+            assert engine.DEFERRED[0] - before >= 4 * 2, "stages 2-5 should have deferred in steps 5 and 6"
+        for a, b in zip(ref6, got2):
             assert torch.equal(a, b)
     finally:
         engine._GRAD_SLOTS.clear()

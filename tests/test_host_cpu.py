@@ -609,3 +609,53 @@ def test_lockstep_emission_of_the_branch_tails_matches_sequential(fake, monkeypa
         assert torch.equal(a[2][k], b[2][k]), k
     for k in a[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_bn_backward_sums_formed_by_the_writing_data_gradient(fake, monkeypatch):
+    """engine: when ONE data gradient writes a unit's d(activation) in one piece, it is asked to form that
+    unit's BatchNorm backward sums (conv_fwd_multi bwd_bn) and the unit's own backward skips its reduction
+    pass (bn_act_backward_multi partials) -- strided phases included; an activation with two gradient
+    writers keeps the reduction.  Host logic on the CPU double, against the same model with the fusion
+    switched off; the kernels are held to the reduction pass on the GPU (tests/test_gpu_multi.py)."""
+    from coclr_amd import engine, ops
+    from coclr_amd.backbone import s3dg
+    monkeypatch.setattr(ops, "SMALL_CHANNEL", 0)        # every layer counts as "large"
+    seen = {"bwd_bn": 0, "partials": 0, "two": 0}
+    real_multi, real_bn = ops.conv_fwd_multi, ops.bn_act_backward_multi
+
+    def spy_conv(calls):
+        seen["bwd_bn"] += sum(1 for c in calls if c.get("bwd_bn") is not None)
+        return real_multi(calls)
+
+    def spy_bn(units):
+        for u in units:
+            if u.get("partials"):
+                seen["partials"] += 1
+                seen["two"] += len(u["partials"]) == 2
+        return real_bn(units)
+
+    monkeypatch.setattr(ops, "conv_fwd_multi", spy_conv)
+    monkeypatch.setattr(ops, "bn_act_backward_multi", spy_bn)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 8, 32, 32, generator=g)
+    results = []
+    for fuse in (True, False):
+        monkeypatch.setattr(engine, "FUSE_BN_REDUCE", fuse)
+        torch.manual_seed(0)
+        m = s3dg.S3D(input_channel=3).train()
+        for k in seen:
+            seen[k] = 0
+        out = m(x)
+        out.square().mean().backward()
+        results.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                        dict(seen)))
+    (oa, ga, sa), (ob, gb, sb) = results
+    assert sb["bwd_bn"] == 0 and sb["partials"] == 0
+    # Conv_1a.bn1 (two strided phases), Conv_2c.bn1 and the conv1 BatchNorms of the separable branches of the
+    # nine blocks whose temporal data gradient has the epilogue
+    assert sa["partials"] >= 2 + 2 * 9 - 4 and sa["two"] == 1, sa
+    assert sa["bwd_bn"] == sa["partials"] + 1, sa
+    assert torch.equal(oa, ob)
+    for k in ga:
+        ref = gb[k]
+        assert (ga[k] - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-8, k
