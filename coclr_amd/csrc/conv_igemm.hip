@@ -1169,7 +1169,7 @@ conv_wino_hw_kernel(const ConvArgs a, const int total_tiles) {
       // refilled for step q+1 as soon as its four MFMAs have gone.
       auto fetch_a_quad = [&](int q, int g, float (&av)[16]) {
         if (ABL & 32) { if (q == 0) { av[4 * g] = av[4 * g + 1] = av[4 * g + 2] = av[4 * g + 3] = 1.f + g; } return; }
-        const float4 v = *reinterpret_cast<const float4*>(
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
             &cur[abase + 2 * q * BM * 16 + ((g + arot) & 3) * 4]);
         av[4 * g + 0] = v.x; av[4 * g + 1] = v.y; av[4 * g + 2] = v.z; av[4 * g + 3] = v.w;
       };
@@ -1390,6 +1390,403 @@ int launch_wino_hw(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   const long total = (long)a.mtiles * a.ntiles;
   const int grid = total < kWinoGrid ? (int)total : kWinoGrid;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, a, (int)total);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// The same F(2x2,3x3) convolution with TWO waves per SIMD (round 4).
+//
+// What bounds conv_wino_hw_kernel is its single wave per SIMD: 256 accumulators leave room for nothing
+// else, and the wave's transform adds, LDS reads and DMA issue run in program order BESIDE its own MFMAs
+// (MFMA pipe busy 47 %, section 4.1 of DESIGN.md).  Here the workgroup keeps its 64(cout) x 64(block
+// positions) tile, its LDS stages and its DMA traffic, but is EIGHT waves: a wave owns 32 couts x 16 block
+// positions as 2 x 16 MFMA tiles of v_mfma_f32_16x16x4_f32 -- 128 accumulators, <= 128 other registers --
+// so a SIMD holds two waves and one's transform / LDS / DMA instructions issue under the other's MFMAs.
+// Per wave and 4-channel step: one patch transform (lane = block position l&15, channel l>>4), 2 x 16
+// weights, 32 MFMAs of 32 cycles -- the same instruction mix per MFMA cycle as the one-wave kernel, the
+// window planes 32 floats out of phase so the four channel planes of a read hit different banks.
+// 16-byte window DMA only (Wi % 4 == 0); the one-wave kernel keeps every other case.
+template <int CC, int PCH>
+__global__ void __launch_bounds__(512)
+conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
+  constexpr int TAPS = 16;
+  constexpr int BM = 64;
+  static_assert(CC == 8, "one window channel per wave");
+  constexpr int W_FLOATS = TAPS * CC * BM;
+  constexpr int QS = CC / 4;
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeS = a.planeS;
+  const int stage_floats = W_FLOATS + CC * planeS;
+  float* redS = smem + 2 * stage_floats;            // [BM][64] statistics partials, never DMA'd over
+  float* redQ = redS + BM * 64;
+  unsigned* wtab = reinterpret_cast<unsigned*>(redQ + BM * 64);   // [PCH][64] window coordinates
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, l15 = lane & 15;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int plane = a.plane;
+  const int WW = a.WW;
+
+  const int nwg = (int)gridDim.x;
+  int tile = (nwg % 8 == 0) ? ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  if (tile >= total_tiles) return;
+
+  const unsigned wvoff = (unsigned)lane * 16u;
+
+  // window coordinates (n, t, h, w-granule) of the granules a lane fetches: the same for every channel
+  if (tid < 64) {
+    const int rowlen = WW >> 2;
+    const int hw = a.WH * rowlen;
+    const int p1 = a.plane1 >> 2;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int e = j * 64 + lane;
+      unsigned crd = 0xffffffffu;
+      if (e < plane) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        int q = e - wn_ * p1;
+        const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
+        const int wh = fdiv(q, a.inv_ww);
+        const int ww = q - wh * rowlen;
+        crd = (unsigned)ww | ((unsigned)wh << 8) | ((unsigned)wt << 16) | ((unsigned)wn_ << 24);
+      }
+      wtab[j * 64 + lane] = crd;
+    }
+  }
+  __syncthreads();
+
+  // block position of this lane inside the box: window offset of the top-left element of its 4x4 patch
+  int lanebase, ptw, pth, ptt, ptn;
+  {
+    const int p = wn * 16 + l15;
+    ptw = p & ((1 << a.lTW) - 1);
+    pth = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    ptt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    ptn = p >> (a.lTW + a.lTH + a.lTT);
+    lanebase = W_FLOATS + ptn * a.plane1 + (ptt * a.WH + pth * 2) * WW + ptw * 2 + kq * planeS + 3;
+  }
+  // weights in LDS: [c][m][16 xi], the four xi quads of row m rotated by m>>2 (see the one-wave kernel)
+  const int abase = (kq * BM + wm * 32 + l15) * 16;
+  const int arot = (l15 >> 2) & 3;
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
+
+  int ntile, n0, ot0, oh0, ow0, cout0;
+  unsigned goff[PCH];
+  __amdgpu_buffer_rsrc_t rx;
+  auto setup = [&](int t) {
+    const int mt = t % a.mtiles;
+    ntile = t / a.mtiles;
+    int r = ntile;
+    const int bw_ = r % a.nbw; r /= a.nbw;
+    const int bh_ = r % a.nbh; r /= a.nbh;
+    const int bt_ = r % a.nbt; r /= a.nbt;
+    n0 = r << a.lTN;
+    ow0 = bw_ << a.lTW; oh0 = bh_ << a.lTH; ot0 = bt_ << a.lTT;
+    cout0 = mt * BM;
+    const int vt0 = ot0, vh0 = oh0 * 2 - 1, vw0 = ow0 * 2 - 4;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const unsigned c = wtab[j * 64 + lane];
+      const int ww = (int)(c & 255u), wh = (int)((c >> 8) & 255u), wt = (int)((c >> 16) & 255u),
+                wn_ = (int)(c >> 24);
+      const int iw = vw0 + 4 * ww, ih = vh0 + wh, it = vt0 + wt, n = n0 + wn_;
+      const bool ok = c != 0xffffffffu && n < a.N && it < a.Ti && (unsigned)ih < (unsigned)a.Hi &&
+                      (unsigned)iw < (unsigned)a.Wi;
+      const long off = (long)wn_ * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw;
+      goff[j] = ok ? (unsigned)off * 4u : OOB;
+    }
+    rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long)n0 * a.x_nstride), 0, BUF_RANGE,
+                                           0x00020000);
+  };
+
+  // DMA of one chunk: 32 weight pieces of 1 KiB (channel row k, quarter) -- wave w moves quarter w&3 of
+  // rows (w>>2) + 2i -- and window channel `wave`
+  auto stage = [&](int cin0, float* sbase) {
+    {
+      const int k0 = wave >> 2, qtr = wave & 3;
+      unsigned soff = (unsigned)(((((long)cin0 + k0) * a.CoutP + cout0) * 16 + qtr * 256) * 4);
+      const unsigned sstep = (unsigned)a.CoutP * 128u;
+      float* dst = sbase + k0 * 1024 + qtr * 256;
+#pragma unroll
+      for (int i = 0; i < CC / 2; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(dst), 16, wvoff, soff, 0, 0);
+        soff += sstep;
+        dst += 2048;
+      }
+    }
+    float* xs = sbase + W_FLOATS + wave * planeS;
+    const int cin = cin0 + wave;
+    if (cin < a.Cin) {
+      const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+      for (int j = 0; j < PCH; ++j)
+        if (j * 64 < plane) dma16_to_lds(rx, xs + j * 256, goff[j], soff);
+    } else {
+#pragma unroll
+      for (int j = 0; j < PCH; ++j)
+        if (j * 64 < plane)
+          *reinterpret_cast<float4*>(&xs[j * 256 + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  const int nchunks = a.nchunks;
+  const bool want_stats = a.stats != nullptr;
+  const unsigned kq_rows = (unsigned)kq * 4u * (unsigned)a.y_cstride * 4u;
+  const unsigned row_bytes = (unsigned)a.yWf * 4u;
+
+  // one instantiation of the tile loop per phase (see below): the branch is wave-uniform and both sides
+  // pass the same barriers in the same order
+  auto run_tiles = [&](auto late_tag) {
+  constexpr bool LATE = decltype(late_tag)::value;
+  bool stored = false;      // an epilogue has issued its output stores
+  setup(tile);
+  stage(0, smem);
+  int G = 0;
+
+  // The two waves of a SIMD (w and w + 4) run HALF A CHUNK out of phase: after the per-chunk barrier both
+  // would read and transform first and multiply afterwards -- in step, so nothing of one hides under the
+  // other.  Waves 4..7 therefore keep the MFMAs of a chunk's last step back (operands stay in registers)
+  // and issue them after the NEXT barrier, while waves 0..3 read and transform; from then on one wave of
+  // the pair multiplies whenever the other prepares.  Nothing is read from LDS late: the stage being
+  // refilled after a barrier was last read before it.
+  for (;;) {
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mb][t][i] = 0.f;
+    float av[2][16], V[16];
+    auto mma_all = [&]() {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          acc[mb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb][t], V[t], acc[mb][t], 0, 0, 0);
+    };
+
+    for (int ch = 0; ch < nchunks; ++ch, ++G) {
+      const float* cur = smem + (G & 1) * stage_floats;
+      // This wave's DMA of the chunk has landed; LDS reads of the other stage are done.  The counter is in
+      // issue order, so at the first chunk of a tile the 16 output stores of the previous tile's epilogue
+      // -- issued AFTER this chunk's DMA -- may stay in flight (vmcnt(16)); __syncthreads() would drain them.
+      if (ch == 0 && stored) __builtin_amdgcn_s_waitcnt(0x4070);
+      else __builtin_amdgcn_s_waitcnt(0x0070);
+      __builtin_amdgcn_s_barrier();
+      if (LATE && ch > 0) mma_all();        // the last step of the previous chunk, before this wave's DMA issue
+      if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((G + 1) & 1) * stage_floats);
+
+      auto fetch_a_quad = [&](int q, int mb, int g, float (&av)[2][16]) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
+            &cur[abase + mb * 256 + 4 * q * BM * 16 + ((g + arot) & 3) * 4]);
+        av[mb][4 * g + 0] = v.x; av[mb][4 * g + 1] = v.y; av[mb][4 * g + 2] = v.z; av[mb][4 * g + 3] = v.w;
+      };
+      auto fetch_d = [&](int q, f32x2 (&dv)[8]) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float* src = &cur[lanebase + rr * WW + 4 * q * planeS];
+          const f32x2 lo = *reinterpret_cast<const f32x2*>(src - 1);
+          const f32x2 mid = *reinterpret_cast<const f32x2*>(src + 1);
+          const f32x2 hi = *reinterpret_cast<const f32x2*>(src + 3);
+          dv[2 * rr].x = lo.y; dv[2 * rr].y = mid.x;
+          dv[2 * rr + 1].x = mid.y; dv[2 * rr + 1].y = hi.x;
+        }
+      };
+      auto transform = [&](const f32x2 (&dv)[8], float (&V)[16]) {
+        f32x2 tl[4], th[4];
+        tl[0] = dv[0] - dv[4]; th[0] = dv[1] - dv[5];
+        tl[1] = dv[2] + dv[4]; th[1] = dv[3] + dv[5];
+        tl[2] = dv[4] - dv[2]; th[2] = dv[5] - dv[3];
+        tl[3] = dv[2] - dv[6]; th[3] = dv[3] - dv[7];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          V[4 * i + 0] = tl[i].x - th[i].x;
+          V[4 * i + 1] = tl[i].y + th[i].x;
+          V[4 * i + 2] = th[i].x - tl[i].y;
+          V[4 * i + 3] = tl[i].y - th[i].y;
+        }
+      };
+      f32x2 dv[8];
+      fetch_d(0, dv);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fetch_a_quad(0, mb, g, av);
+#pragma unroll
+      for (int q = 0; q < QS; ++q) {
+        transform(dv, V);
+        if (q + 1 < QS) fetch_d(q + 1, dv);
+        if (q + 1 < QS) {
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                acc[mb][4 * g + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb][4 * g + k], V[4 * g + k],
+                                                                         acc[mb][4 * g + k], 0, 0, 0);
+              fetch_a_quad(q + 1, mb, g, av);
+            }
+        } else if (!LATE) {
+          mma_all();
+        }
+      }
+    }
+    if (LATE) mma_all();
+
+    // ---- epilogue: Y = A^T M A into registers; hand the LDS stream to the next tile ---------
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.y + (long)n0 * a.y_nstride), 0, BUF_RANGE, 0x00020000);
+    unsigned yvoff;
+    bool pvalid;
+    {
+      const int n = n0 + ptn, ot = ot0 + ptt, oh = oh0 + pth, ow = ow0 + ptw;   // block coords
+      pvalid = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
+      const long e = (long)ptn * a.y_nstride + ((long)ot * a.yHf + 2 * oh) * a.yWf + 2 * ow;
+      yvoff = pvalid ? (unsigned)(e * 4) + kq_rows : OOB;
+    }
+    const int e_ntile = ntile, e_cout0 = cout0;
+    const int next = tile + nwg;
+    const bool more = next < total_tiles;
+    if (more) {
+      setup(next);
+      stage(0, smem + (G & 1) * stage_floats);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the DMA stays in front of the stores below (vmcnt(16) above)
+    stored = true;
+
+    auto emit = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int mb = e >> 2, i = e & 3;
+        const int rowu = wm * 32 + mb * 16 + i;        // wave-uniform part of the row
+        const int ml = rowu + 4 * kq;
+        float r0[4], r1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float m0 = agpr_read(acc[mb][0 + j][i]), m1 = agpr_read(acc[mb][4 + j][i]),
+                      m2 = agpr_read(acc[mb][8 + j][i]), m3 = agpr_read(acc[mb][12 + j][i]);
+          r0[j] = (m0 + m1) + m2;
+          r1[j] = (m1 - m2) - m3;
+        }
+        float v00 = (r0[0] + r0[1]) + r0[2], v01 = (r0[1] - r0[2]) - r0[3];
+        float v10 = (r1[0] + r1[1]) + r1[2], v11 = (r1[1] - r1[2]) - r1[3];
+        if (MODE == 2) {
+          const int co = e_cout0 + ml;
+          const bool cok = co < a.Cout;
+          if (a.accumulate) {
+            const unsigned soff = (unsigned)(e_cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+            const unsigned vo0 = cok ? yvoff : OOB;
+            const unsigned vo1 = cok && pvalid ? yvoff + row_bytes : OOB;
+            const u32x2 o0 = __builtin_amdgcn_raw_buffer_load_b64(ry, vo0, soff, 0);
+            const u32x2 o1 = __builtin_amdgcn_raw_buffer_load_b64(ry, vo1, soff, 0);
+            v00 += __uint_as_float(o0.x); v01 += __uint_as_float(o0.y);
+            v10 += __uint_as_float(o1.x); v11 += __uint_as_float(o1.y);
+          }
+        }
+        if (MODE != 0 && (MODE == 1 || want_stats)) {
+          float s = 0.f, ss = 0.f;
+          if (pvalid) {
+            s = (v00 + v01) + (v10 + v11);
+            ss = (v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11);
+          }
+          redS[ml * 64 + wn * 16 + l15] = s;
+          redQ[ml * 64 + wn * 16 + l15] = ss;
+        }
+        if (MODE == 2) {
+          const int co = e_cout0 + ml;
+          const bool cok = co < a.Cout;
+          float bia = 0.f, sc = 1.f, sf = 0.f;
+          if (a.bias && cok) bia = a.bias[co];
+          if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+          v00 = (v00 + bia) * sc + sf; v01 = (v01 + bia) * sc + sf;
+          v10 = (v10 + bia) * sc + sf; v11 = (v11 + bia) * sc + sf;
+          if (a.relu) {
+            v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f);
+          }
+        }
+        {
+          // stored at once: with two waves per SIMD there is no register room to park the outputs
+          const unsigned soff = (unsigned)(e_cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+          const bool cok = e_cout0 + ml < a.Cout;
+          u32x2 s0, s1;
+          s0.x = __float_as_uint(v00); s0.y = __float_as_uint(v01);
+          s1.x = __float_as_uint(v10); s1.y = __float_as_uint(v11);
+          __builtin_amdgcn_raw_buffer_store_b64(s0, ry, cok ? yvoff : OOB, soff, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(s1, ry, cok && pvalid ? yvoff + row_bytes : OOB, soff, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    const bool fancy = a.bias || a.ep_scale || a.relu || a.accumulate;
+    if (fancy) emit(std::integral_constant<int, 2>{});
+    else if (want_stats) emit(std::integral_constant<int, 1>{});
+    else emit(std::integral_constant<int, 0>{});
+
+    if (want_stats) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // the partials are in LDS; stores and DMA stay in flight
+      __builtin_amdgcn_s_barrier();
+      if (tid < 256) {
+        // thread t: row t>>2, quarter t&3 of its 64 partials; the quarters meet through DPP
+        const int row = tid >> 2, qtr = tid & 3;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 ps = *reinterpret_cast<const float4*>(&redS[row * 64 + qtr * 16 + 4 * k]);
+          const float4 pq = *reinterpret_cast<const float4*>(&redQ[row * 64 + qtr * 16 + 4 * k]);
+          s += (ps.x + ps.y) + (ps.z + ps.w);
+          ss += (pq.x + pq.y) + (pq.z + pq.w);
+        }
+        s += __builtin_amdgcn_update_dpp(0.f, s, 0xB1, 0xf, 0xf, true);
+        s += __builtin_amdgcn_update_dpp(0.f, s, 0x4E, 0xf, 0xf, true);
+        ss += __builtin_amdgcn_update_dpp(0.f, ss, 0xB1, 0xf, 0xf, true);
+        ss += __builtin_amdgcn_update_dpp(0.f, ss, 0x4E, 0xf, 0xf, true);
+        const int co = e_cout0 + row;
+        if (qtr == 0 && co < a.Cout) {
+          a.stats[(long)co * a.ntiles + e_ntile] = s;
+          a.stats[((long)a.Cout + co) * a.ntiles + e_ntile] = ss;
+        }
+      }
+    }
+    if (!more) break;
+    tile = next;
+  }
+  };
+  if (wave >= 4) run_tiles(std::true_type{});
+  else run_tiles(std::false_type{});
+}
+
+template <int CC, int PCH>
+int launch_wino_hw8(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
+  if (p.WW > 255 || p.WH > 255 || p.WT > 255 || p.lTN > 7) return COCLR_EINVAL;
+  a.mtiles = cdiv(a.Cout, 64);
+  const int wwp = 2 * (1 << p.lTW) + 8;
+  a.WW = wwp;
+  a.plane1 = p.WT * p.WH * wwp;
+  a.plane = (a.plane1 << p.lTN) / 4;                 // granules
+  if (a.plane > PCH * 64) return COCLR_EINVAL;
+  // + 32 floats: the four channel planes a patch read touches sit half the banks apart
+  a.planeS = cdiv(a.plane, 64) * 256 + 32;
+  a.inv_plane1 = 1.0f / (float)(a.plane1 / 4);
+  a.inv_hw = 1.0f / (float)(p.WH * (wwp / 4));
+  a.inv_ww = 1.0f / (float)(wwp / 4);
+  a.nchunks = cdiv(a.Cin, CC);
+  const size_t stage = ((size_t)16 * CC * 64 + (size_t)CC * a.planeS) * sizeof(float);
+  const size_t lds = 2 * stage + (size_t)2 * 64 * 64 * sizeof(float) + (size_t)PCH * 64 * sizeof(unsigned);
+  if (lds > 160 * 1024) return COCLR_EINVAL;
+  auto kern = conv_wino_hw8_kernel<CC, PCH>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  const long total = (long)a.mtiles * a.ntiles;
+  const int grid = total < kWinoGrid ? (int)total : kWinoGrid;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, a, (int)total);
   COCLR_LAUNCH_CHECK();
   return 0;
 }
@@ -2304,6 +2701,12 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
         const int gran = ((p.WT * p.WH * (2 * (1 << p.lTW) + 8)) << p.lTN) / 4;
         const bool x16 = !x16_off && p.lTW >= 1 && (p.Wi % 4) == 0 && (a.x_cstride % 4) == 0 &&
                          (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 && gran <= 192;
+        // two waves per SIMD (conv_wino_hw8_kernel): COCLR_WINO_W8=1
+        static const bool w8 = getenv("COCLR_WINO_W8") && atoi(getenv("COCLR_WINO_W8")) != 0;
+        if (x16 && w8) {
+          int rc8 = launch_wino_hw8<8, 3>(a, p, stream);
+          if (rc8 != COCLR_EINVAL) return rc8;
+        }
         if (x16) {
 #ifdef COCLR_WINO_ABLATE
           // timing ablations (wrong results by design; build with -DCOCLR_WINO_ABLATE, tools/wino_ablate.sh):
