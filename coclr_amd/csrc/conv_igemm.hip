@@ -1539,21 +1539,52 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
   const unsigned kq_rows = (unsigned)kq * 4u * (unsigned)a.y_cstride * 4u;
   const unsigned row_bytes = (unsigned)a.yWf * 4u;
 
+  // fold the [BM][64] statistics partials of a finished tile: thread t (0..255 of the four waves that do
+  // it): row t>>2, quarter t&3 of its 64 partials; the quarters meet through DPP
+  auto fold_stats = [&](int t, int f_cout0, int f_ntile) {
+    const int row = t >> 2, qtr = t & 3;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 ps = *reinterpret_cast<const f32x4*>(&redS[row * 64 + qtr * 16 + 4 * k]);
+      const f32x4 pq = *reinterpret_cast<const f32x4*>(&redQ[row * 64 + qtr * 16 + 4 * k]);
+      s += (ps.x + ps.y) + (ps.z + ps.w);
+      ss += (pq.x + pq.y) + (pq.z + pq.w);
+    }
+    s += __builtin_amdgcn_update_dpp(0.f, s, 0xB1, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0.f, s, 0x4E, 0xf, 0xf, true);
+    ss += __builtin_amdgcn_update_dpp(0.f, ss, 0xB1, 0xf, 0xf, true);
+    ss += __builtin_amdgcn_update_dpp(0.f, ss, 0x4E, 0xf, 0xf, true);
+    const int co = f_cout0 + row;
+    if (qtr == 0 && co < a.Cout) {
+      a.stats[(long)co * a.ntiles + f_ntile] = s;
+      a.stats[((long)a.Cout + co) * a.ntiles + f_ntile] = ss;
+    }
+  };
+  // With >= 2 chunks per tile the fold needs no barrier of its own: the partials a tile's epilogue leaves in
+  // LDS are folded by waves 4..7 after the NEXT tile's first chunk barrier (every wave has written by then,
+  // and the next epilogue writes them again only behind a later barrier).
+  const bool fold_later = a.nchunks >= 2;
+
   // one instantiation of the tile loop per phase (see below): the branch is wave-uniform and both sides
   // pass the same barriers in the same order
   auto run_tiles = [&](auto late_tag) {
   constexpr bool LATE = decltype(late_tag)::value;
   bool stored = false;      // an epilogue has issued its output stores
+  bool fold_due = false;    // ... and left statistics partials to fold
+  int f_cout0 = 0, f_ntile = 0;
   setup(tile);
   stage(0, smem);
   int G = 0;
 
-  // The two waves of a SIMD (w and w + 4) run HALF A CHUNK out of phase: after the per-chunk barrier both
+  // The two waves of a SIMD (w and w + 4) run A QUARTER CHUNK out of phase: after the per-chunk barrier both
   // would read and transform first and multiply afterwards -- in step, so nothing of one hides under the
-  // other.  Waves 4..7 therefore keep the MFMAs of a chunk's last step back (operands stay in registers)
+  // other.  Waves 4..7 therefore keep the last 16 MFMAs of a chunk back (their operands stay in registers)
   // and issue them after the NEXT barrier, while waves 0..3 read and transform; from then on one wave of
-  // the pair multiplies whenever the other prepares.  Nothing is read from LDS late: the stage being
-  // refilled after a barrier was last read before it.
+  // the pair multiplies while the other prepares.  Nothing is read from LDS late: the stage being refilled
+  // after a barrier was last read before it.
+  // Operands: one 16-register weight set whose quads are refilled, as soon as their four MFMAs have issued,
+  // with the weights of the next 16-cout half / channel step (12 MFMAs = 384 cycles before their next use).
   for (;;) {
     f32x4 acc[2][16];
 #pragma unroll
@@ -1562,13 +1593,13 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
       for (int t = 0; t < 16; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[mb][t][i] = 0.f;
-    float av[2][16], V[16];
-    auto mma_all = [&]() {
+    float av[16], V[16];
+    // the 4 MFMAs of weight quad g on accumulator half mb
+    auto mma_quad = [&](int mb, int g) {
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-          acc[mb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb][t], V[t], acc[mb][t], 0, 0, 0);
+      for (int k = 0; k < 4; ++k)
+        acc[mb][4 * g + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * g + k], V[4 * g + k],
+                                                                 acc[mb][4 * g + k], 0, 0, 0);
     };
 
     for (int ch = 0; ch < nchunks; ++ch, ++G) {
@@ -1579,13 +1610,13 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
       if (ch == 0 && stored) __builtin_amdgcn_s_waitcnt(0x4070);
       else __builtin_amdgcn_s_waitcnt(0x0070);
       __builtin_amdgcn_s_barrier();
-      if (LATE && ch > 0) mma_all();        // the last step of the previous chunk, before this wave's DMA issue
-      if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((G + 1) & 1) * stage_floats);
+      if (LATE && ch == 0 && fold_due) { fold_stats(tid - 256, f_cout0, f_ntile); fold_due = false; }
+      if (!LATE && ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((G + 1) & 1) * stage_floats);
 
-      auto fetch_a_quad = [&](int q, int mb, int g, float (&av)[2][16]) {
+      auto fetch_a_quad = [&](int q, int mb, int g) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(
             &cur[abase + mb * 256 + 4 * q * BM * 16 + ((g + arot) & 3) * 4]);
-        av[mb][4 * g + 0] = v.x; av[mb][4 * g + 1] = v.y; av[mb][4 * g + 2] = v.z; av[mb][4 * g + 3] = v.w;
+        av[4 * g + 0] = v.x; av[4 * g + 1] = v.y; av[4 * g + 2] = v.z; av[4 * g + 3] = v.w;
       };
       auto fetch_d = [&](int q, f32x2 (&dv)[8]) {
 #pragma unroll
@@ -1614,31 +1645,35 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
       };
       f32x2 dv[8];
       fetch_d(0, dv);
+      if (LATE && ch > 0) {
+        // the last 16 MFMAs of the previous chunk; their weight quads make room for this chunk's first ones
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+        for (int g = 0; g < 4; ++g) { mma_quad(1, g); fetch_a_quad(0, 0, g); }
+      } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) fetch_a_quad(0, mb, g, av);
+        for (int g = 0; g < 4; ++g) fetch_a_quad(0, 0, g);
+      }
+      // waves 4..7 issue their DMA behind the held-back MFMAs: it runs under the other waves' DMA issue
+      if (LATE && ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((G + 1) & 1) * stage_floats);
 #pragma unroll
       for (int q = 0; q < QS; ++q) {
         transform(dv, V);
         if (q + 1 < QS) fetch_d(q + 1, dv);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { mma_quad(0, g); fetch_a_quad(q, 1, g); }
         if (q + 1 < QS) {
 #pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k)
-                acc[mb][4 * g + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb][4 * g + k], V[4 * g + k],
-                                                                         acc[mb][4 * g + k], 0, 0, 0);
-              fetch_a_quad(q + 1, mb, g, av);
-            }
+          for (int g = 0; g < 4; ++g) { mma_quad(1, g); fetch_a_quad(q + 1, 0, g); }
         } else if (!LATE) {
-          mma_all();
+#pragma unroll
+          for (int g = 0; g < 4; ++g) mma_quad(1, g);
         }
       }
     }
-    if (LATE) mma_all();
+    if (LATE) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) mma_quad(1, g);
+    }
 
     // ---- epilogue: Y = A^T M A into registers; hand the LDS stream to the next tile ---------
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
@@ -1731,32 +1766,21 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
     else emit(std::integral_constant<int, 0>{});
 
     if (want_stats) {
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // the partials are in LDS; stores and DMA stay in flight
-      __builtin_amdgcn_s_barrier();
-      if (tid < 256) {
-        // thread t: row t>>2, quarter t&3 of its 64 partials; the quarters meet through DPP
-        const int row = tid >> 2, qtr = tid & 3;
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 ps = *reinterpret_cast<const float4*>(&redS[row * 64 + qtr * 16 + 4 * k]);
-          const float4 pq = *reinterpret_cast<const float4*>(&redQ[row * 64 + qtr * 16 + 4 * k]);
-          s += (ps.x + ps.y) + (ps.z + ps.w);
-          ss += (pq.x + pq.y) + (pq.z + pq.w);
-        }
-        s += __builtin_amdgcn_update_dpp(0.f, s, 0xB1, 0xf, 0xf, true);
-        s += __builtin_amdgcn_update_dpp(0.f, s, 0x4E, 0xf, 0xf, true);
-        ss += __builtin_amdgcn_update_dpp(0.f, ss, 0xB1, 0xf, 0xf, true);
-        ss += __builtin_amdgcn_update_dpp(0.f, ss, 0x4E, 0xf, 0xf, true);
-        const int co = e_cout0 + row;
-        if (qtr == 0 && co < a.Cout) {
-          a.stats[(long)co * a.ntiles + e_ntile] = s;
-          a.stats[((long)a.Cout + co) * a.ntiles + e_ntile] = ss;
-        }
+      if (fold_later) {
+        fold_due = true; f_cout0 = e_cout0; f_ntile = e_ntile;
+      } else {
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // the partials are in LDS; stores and DMA stay in flight
+        __builtin_amdgcn_s_barrier();
+        if (tid < 256) fold_stats(tid, e_cout0, e_ntile);
       }
     }
     if (!more) break;
     tile = next;
+  }
+  if (want_stats && fold_later) {           // the last tile's partials
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    if (LATE && fold_due) fold_stats(tid - 256, f_cout0, f_ntile);
   }
   };
   if (wave >= 4) run_tiles(std::true_type{});
