@@ -1472,13 +1472,13 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
   __syncthreads();
 
   // block position of this lane inside the box: window offset of the top-left element of its 4x4 patch
-  int lanebase, ptw, pth, ptt, ptn;
+  int lanebase;
   {
     const int p = wn * 16 + l15;
-    ptw = p & ((1 << a.lTW) - 1);
-    pth = (p >> a.lTW) & ((1 << a.lTH) - 1);
-    ptt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
-    ptn = p >> (a.lTW + a.lTH + a.lTT);
+    const int ptw = p & ((1 << a.lTW) - 1);
+    const int pth = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int ptt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int ptn = p >> (a.lTW + a.lTH + a.lTT);
     lanebase = W_FLOATS + ptn * a.plane1 + (ptt * a.WH + pth * 2) * WW + ptw * 2 + kq * planeS + 3;
   }
   // weights in LDS: [c][m][16 xi], the four xi quads of row m rotated by m>>2 (see the one-wave kernel)
@@ -1543,7 +1543,6 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
 
   const int nchunks = a.nchunks;
   const bool want_stats = a.stats != nullptr;
-  const unsigned kq_rows = (unsigned)kq * 4u * (unsigned)a.y_cstride * 4u;
   const unsigned row_bytes = (unsigned)a.yWf * 4u;
 
   // fold the [BM][64] statistics partials of a finished tile: thread t (0..255 of the four waves that do
@@ -1709,13 +1708,26 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
     // ---- epilogue: Y = A^T M A into registers; hand the LDS stream to the next tile ---------
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.y + (long)n0 * a.y_nstride), 0, BUF_RANGE, 0x00020000);
+    // The lane's position is RE-DERIVED here from the thread index (behind an opaque asm, so the values are
+    // not loop-invariant to the compiler): kept live across the chunk loop they are spilled, and a scratch
+    // reload in the epilogue is a VMEM load the compiler waits for with vmcnt(0) -- in front of every pair of
+    // output stores, which then go out one round trip at a time.
     unsigned yvoff;
     bool pvalid;
+    int kq_e, l15_e;
     {
+      int lane_e = (int)threadIdx.x & 63;
+      asm volatile("" : "+v"(lane_e));
+      kq_e = lane_e >> 4; l15_e = lane_e & 15;
+      const int p = wn * 16 + l15_e;
+      const int ptw = p & ((1 << a.lTW) - 1);
+      const int pth = (p >> a.lTW) & ((1 << a.lTH) - 1);
+      const int ptt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+      const int ptn = p >> (a.lTW + a.lTH + a.lTT);
       const int n = n0 + ptn, ot = ot0 + ptt, oh = oh0 + pth, ow = ow0 + ptw;   // block coords
       pvalid = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
       const long e = (long)ptn * a.y_nstride + ((long)ot * a.yHf + 2 * oh) * a.yWf + 2 * ow;
-      yvoff = pvalid ? (unsigned)(e * 4) + kq_rows : OOB;
+      yvoff = pvalid ? (unsigned)(e * 4) + (unsigned)kq_e * 4u * (unsigned)a.y_cstride * 4u : OOB;
     }
     const int e_ntile = ntile, e_cout0 = cout0;
     const int next = tile + nwg;
@@ -1733,7 +1745,7 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
       for (int e = 0; e < 8; ++e) {
         const int mb = e >> 2, i = e & 3;
         const int rowu = wm * 32 + mb * 16 + i;        // wave-uniform part of the row
-        const int ml = rowu + 4 * kq;
+        const int ml = rowu + 4 * kq_e;
         float r0[4], r1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1763,8 +1775,8 @@ conv_wino_hw8_kernel(const ConvArgs a, const int total_tiles) {
             s = (v00 + v01) + (v10 + v11);
             ss = (v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11);
           }
-          redS[ml * 64 + wn * 16 + l15] = s;
-          redQ[ml * 64 + wn * 16 + l15] = ss;
+          redS[ml * 64 + wn * 16 + l15_e] = s;
+          redQ[ml * 64 + wn * 16 + l15_e] = ss;
         }
         if (MODE == 2) {
           const int co = e_cout0 + ml;
@@ -2770,8 +2782,10 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
         const int gran = ((p.WT * p.WH * (2 * (1 << p.lTW) + 8)) << p.lTN) / 4;
         const bool x16 = !x16_off && p.lTW >= 1 && (p.Wi % 4) == 0 && (a.x_cstride % 4) == 0 &&
                          (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 && gran <= 192;
-        // two waves per SIMD (conv_wino_hw8_kernel): COCLR_WINO_W8=1
-        static const bool w8 = getenv("COCLR_WINO_W8") && atoi(getenv("COCLR_WINO_W8")) != 0;
+        // two waves per SIMD (conv_wino_hw8_kernel) wherever it applies; COCLR_WINO_W8=0 (read per call:
+        // an A/B and test switch) keeps the one-wave kernel
+        const char* w8env = getenv("COCLR_WINO_W8");
+        const bool w8 = !(w8env && w8env[0] == '0');
         if (x16 && w8) {
           int rc8 = launch_wino_hw8<8, 3>(a, p, stream);
           if (rc8 != COCLR_EINVAL) return rc8;

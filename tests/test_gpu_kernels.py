@@ -641,12 +641,16 @@ WINO_HW_CASES = [(2, 64, 192, (2, 32, 32)), (2, 192, 208, (4, 16, 16)), (3, 48, 
                  (2, 24, 64, (2, 12, 20)), (9, 40, 64, (3, 4, 4))]
 
 
+@pytest.mark.parametrize("waves", ["two_per_simd", "one_per_simd"])
 @pytest.mark.parametrize("case", WINO_HW_CASES, ids=lambda c: "%d_%d_%d_%s" % c)
-def test_conv_spatial_winograd(case, algo=1):
+def test_conv_spatial_winograd(case, waves, monkeypatch, algo=1):
     """(1,3,3) stride-1 pad-1 convolutions through Winograd F(2x2,3x3) (algo = 1): forward with
     BatchNorm partial sums, accumulate form, fused affine+ReLU epilogue, and the data gradient --
-    ragged channel counts, maps that are not a power of two, boxes spanning frames and samples."""
+    ragged channel counts, maps that are not a power of two, boxes spanning frames and samples.
+    Both kernels: conv_wino_hw8_kernel (two waves per SIMD; rows of whole 16-byte granules and channel
+    counts that are multiples of 8, everything else falls through) and conv_wino_hw_kernel."""
     from coclr_amd import ops, engine
+    monkeypatch.setenv("COCLR_WINO_W8", "1" if waves == "two_per_simd" else "0")
     N, Cin, Cout, dims = case
     k, s, p = (1, 3, 3), (1, 1, 1), (0, 1, 1)
     torch.manual_seed(7)
