@@ -395,7 +395,7 @@ def test_engine_with_the_sums_epilogue_matches_the_reduction_pass(monkeypatch):
 
     monkeypatch.setattr(ops, "bn_act_backward_multi", spy)
     g = torch.Generator(device="cuda").manual_seed(9)
-    x = torch.randn(16, 3, 16, 64, 64, device="cuda", generator=g)
+    x = torch.randn(16, 3, 32, 64, 64, device="cuda", generator=g)     # Conv_2c: 65536 values per channel
     grads = []
     for fuse in (False, True):
         monkeypatch.setattr(engine, "FUSE_BN_REDUCE", fuse)
