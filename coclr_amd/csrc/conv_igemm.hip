@@ -367,8 +367,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bid, cons
   float* red = smem;  // [4 (wn, 16-lane row)][BM][2], reused after the main loop
   if (want_stats) __syncthreads();
 
-  auto emit = [&](auto acc_tag) {
+  // FANCY: bias / affine / ReLU asked for (inference epilogue).  The plain form must not even CONTAIN the
+  // per-row coefficient loads: a conditional global load in the store loop makes the compiler wait vmcnt(0)
+  // in front of every row's stores, i.e. for all earlier stores to land -- sixteen memory round trips per tile.
+  auto emit = [&](auto acc_tag, auto fancy_tag) {
     constexpr bool ACCUM = decltype(acc_tag)::value;
+    constexpr bool FANCY = decltype(fancy_tag)::value;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       // accumulate: ALL old values of this row block first -- one round trip; loaded next to its store,
@@ -396,8 +400,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bid, cons
         const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
         float s = 0.f, ss = 0.f;
         float bia = 0.f, sc = 1.f, sf = 0.f;
-        if (a.bias && cok) bia = a.bias[co];
-        if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        if (FANCY) {
+          if (a.bias && cok) bia = a.bias[co];
+          if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        }
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           const unsigned vo = cok ? yvoff[nf] : OOB;
@@ -405,9 +411,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bid, cons
           if (ACCUM) v += old[ACCUM ? i : 0][ACCUM ? nf : 0];
           const float vm = pvalid[nf] ? v : 0.f;
           s += vm; ss += vm * vm;
-          v += bia;
-          v = v * sc + sf;
-          if (a.relu) v = fmaxf(v, 0.f);
+          if (FANCY) {
+            v += bia;
+            v = v * sc + sf;
+            if (a.relu) v = fmaxf(v, 0.f);
+          }
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vo, soff, 0);
         }
         if (want_stats) {
@@ -471,9 +479,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bid, cons
       }
     }
   };
+  const bool fancy = a.bias || a.ep_scale || a.relu;
   if (a.bwd_y) emit_bwd();
-  else if (a.accumulate) emit(std::true_type{});
-  else emit(std::false_type{});
+  else if (fancy) { if (a.accumulate) emit(std::true_type{}, std::true_type{}); else emit(std::false_type{}, std::true_type{}); }
+  else if (a.accumulate) emit(std::true_type{}, std::false_type{});
+  else emit(std::false_type{}, std::false_type{});
 
   if (want_stats) {
     __syncthreads();
@@ -751,8 +761,9 @@ __device__ __forceinline__ void conv_wino_t_body(const ConvArgs& a, int bid, con
   float* red = smem;
   if (want_stats) __syncthreads();
 
-  auto emit = [&](auto acc_tag) {
+  auto emit = [&](auto acc_tag, auto fancy_tag) {       // FANCY: see conv_igemm_body
     constexpr bool ACCUM = decltype(acc_tag)::value;
+    constexpr bool FANCY = decltype(fancy_tag)::value;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
@@ -764,8 +775,10 @@ __device__ __forceinline__ void conv_wino_t_body(const ConvArgs& a, int bid, con
         const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
         float s = 0.f, ss = 0.f;
         float bia = 0.f, sc = 1.f, sf = 0.f;
-        if (a.bias && cok) bia = a.bias[co];
-        if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        if (FANCY) {
+          if (a.bias && cok) bia = a.bias[co];
+          if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        }
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           const float m0 = acc[mf][nf][0][i], m1 = acc[mf][nf][1][i], m2 = acc[mf][nf][2][i],
@@ -779,9 +792,11 @@ __device__ __forceinline__ void conv_wino_t_body(const ConvArgs& a, int bid, con
           }
           const float u0 = pvalid[nf] ? v0 : 0.f, u1 = p2valid[nf] ? v1 : 0.f;
           s += u0 + u1; ss += u0 * u0 + u1 * u1;
-          v0 = (v0 + bia) * sc + sf;
-          v1 = (v1 + bia) * sc + sf;
-          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          if (FANCY) {
+            v0 = (v0 + bia) * sc + sf;
+            v1 = (v1 + bia) * sc + sf;
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          }
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), ry, vo0, soff, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), ry, vo1, soff, 0);
         }
@@ -859,9 +874,11 @@ __device__ __forceinline__ void conv_wino_t_body(const ConvArgs& a, int bid, con
       }
     }
   };
+  const bool fancy = a.bias || a.ep_scale || a.relu;
   if (a.bwd_y) emit_bwd();
-  else if (a.accumulate) emit(std::true_type{});
-  else emit(std::false_type{});
+  else if (fancy) { if (a.accumulate) emit(std::true_type{}, std::true_type{}); else emit(std::false_type{}, std::true_type{}); }
+  else if (a.accumulate) emit(std::true_type{}, std::false_type{});
+  else emit(std::false_type{}, std::false_type{});
 
   if (want_stats) {
     __syncthreads();
