@@ -2036,22 +2036,25 @@ conv_stem_kernel(const ConvArgs a, const int nboxes) {
         goff[jj] = (ok && pre[jj] != OOB) ? pre[jj] + sbox : OOB;
       }
     } else {
+      // gathered samples (the key encoder's shuffled batch): ALL index loads first, unconditionally (clamped),
+      // then one wait -- a load inside each element's `if (ok)` is five dependent memory round trips per box
+      long ns[PW];
+#pragma unroll
+      for (int jj = 0; jj < PW; ++jj) {
+        const int wn_ = (int)(wcoord[jj] & 255u);
+        const int n = n0 + wn_;
+        ns[jj] = gather ? (long)a.n_index[n < a.N ? n : a.N - 1] : (long)wn_;
+      }
 #pragma unroll
       for (int jj = 0; jj < PW; ++jj) {
         const unsigned wc = wcoord[jj];
-        const int wn_ = (int)(wc & 255u);
-        const int n = n0 + wn_;
+        const int n = n0 + (int)(wc & 255u);
         const int it = vt0 + (int)((wc >> 8) & 255u);
         const int ih = vh0 + (int)((wc >> 16) & 255u);
         const int iw = vw0 + (int)(wc >> 24);
         const bool ok = wc != 0xffffffffu && n < a.N && (unsigned)it < (unsigned)a.Ti &&
                         (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-        unsigned off = OOB;
-        if (ok) {
-          const long ns = gather ? (long)a.n_index[n] : (long)wn_;
-          off = (unsigned)((ns * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4);
-        }
-        goff[jj] = off;
+        goff[jj] = ok ? (unsigned)((ns[jj] * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4) : OOB;
       }
     }
 #pragma unroll
@@ -2134,7 +2137,11 @@ conv_stem_kernel(const ConvArgs a, const int nboxes) {
                                 oh0 + pth[nf] < a.Ho && ow0 + ptw[nf] < a.Wo);
       yvoff[nf] = pvalid[nf] ? ylane[nf] + ybox : OOB;
     }
-    {
+    // The plain form (training forward: statistics, nothing else) must not CONTAIN the conditional coefficient /
+    // accumulate loads: with them in the loop the compiler waits vmcnt(0) in front of every store, i.e. for all
+    // earlier stores of the box to land -- 32 memory round trips per box.
+    auto emit = [&](auto fancy_tag) {
+      constexpr bool FANCY = decltype(fancy_tag)::value;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rowu = wm * 32 + (i & 3) + 8 * (i >> 2);
@@ -2142,23 +2149,29 @@ conv_stem_kernel(const ConvArgs a, const int nboxes) {
         const bool cok = co < a.Cout;
         const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
         float bia = 0.f, sc = 1.f, sf = 0.f;
-        if (a.bias && cok) bia = a.bias[co];
-        if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        if (FANCY) {
+          if (a.bias && cok) bia = a.bias[co];
+          if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        }
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           const unsigned vo = cok ? yvoff[nf] : OOB;
           float v = acc[nf][i];
-          if (a.accumulate)
+          if (FANCY && a.accumulate)
             v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo, soff, 0));
           const float vm = pvalid[nf] ? v : 0.f;
           st_s[i] += vm; st_q[i] += vm * vm;
-          v += bia;
-          v = v * sc + sf;
-          if (a.relu) v = fmaxf(v, 0.f);
+          if (FANCY) {
+            v += bia;
+            v = v * sc + sf;
+            if (a.relu) v = fmaxf(v, 0.f);
+          }
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, vo, soff, 0);
         }
       }
-    }
+    };
+    if (a.bias || a.ep_scale || a.relu || a.accumulate) emit(std::true_type{});
+    else emit(std::false_type{});
     // every wave's share of the next window has landed (waited above) and every wave is done
     // reading this one (its MFMAs have issued): a bare barrier, no memory-counter drain
     asm volatile("s_barrier" ::: "memory");
