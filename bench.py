@@ -614,8 +614,8 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic,
-                    "kernel": "conv_wino_hw_kernel<8,3,true> Winograd F(2x2,3x3), 16-byte window DMA "
-                              "(Conv_2c.conv1 64->192, "
+                    "kernel": "conv_wino_hw8_kernel<8,3> Winograd F(2x2,3x3), two waves per SIMD, 16-byte "
+                              "window DMA (Conv_2c.conv1 64->192, "
                               "%dx%dx%d, N=%d; the query encoder's forward launches inside the timed "
                               "steps, sharing the chip with the key-encoder stream)" % (tq, hq, hq, B),
                     "launches_timed": nk, "avg_launch_ms": round(kms, 4),

@@ -5,7 +5,8 @@ this rocprofv3 on gfx950) and its MFMA-busy fraction."""
 import json, re, sys
 src, dst = sys.argv[1], sys.argv[2]
 txt = open(src).read()
-blk = txt[txt.index("void conv_wino_hw_kernel"):]
+key = "void conv_wino_hw8_kernel" if "void conv_wino_hw8_kernel" in txt else "void conv_wino_hw_kernel"
+blk = txt[txt.index(key):]
 blk = blk[:blk.index("\nvoid ", 5)] if "\nvoid " in blk[5:] else blk
 name = blk.splitlines()[0].strip()
 val = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\w+)\s+([0-9.]+)\s+\(n=", blk, re.M)}
