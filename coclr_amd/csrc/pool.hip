@@ -214,8 +214,9 @@ maxpool3d_tiled_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
 // with an LDS-only barrier in between.  Same addends in the same order as the generic form.
 template <int PT, int PH, int PW, int KQ>
 struct ClassLoads {
-  int i[PT * PH * PW][KQ];
-  float v[PT * PH * PW][KQ];
+  int i[PT * PH * PW][KQ];      // the arg-max index AS LOADED (-1: no element), added to b only when applied:
+  int b[PT * PH * PW][KQ];      // arithmetic on the loaded value next to the load would make every class wait
+  float v[PT * PH * PW][KQ];    // for its own round trip before the next class's loads are even issued
 };
 
 template <int PT, int PH, int PW, int KQ>
@@ -237,6 +238,7 @@ __device__ __forceinline__ void class_load(ClassLoads<PT, PH, PW, KQ>& L, const 
         for (int k = 0; k < KQ; ++k) {
           const int q = threadIdx.x + k * 256;
           L.i[cls][k] = -1;
+          L.b[cls][k] = 0;
           L.v[cls][k] = 0.f;
           if (q < gcount * csize) {
             const int gi = q / csize;
@@ -247,7 +249,8 @@ __device__ __forceinline__ void class_load(ClassLoads<PT, PH, PW, KQ>& L, const 
             const int o = ((a * PT + ct) * g.Ho + (b * PH + ch)) * g.Wo + (cc * PW + cw);
             const int pl = pl0 + gi;
             const int n = pl / g.C, c = pl - n * g.C;
-            L.i[cls][k] = gi * Si + idx[(long)pl * So + o] - (pl % tfold) * Si;
+            L.b[cls][k] = gi * Si - (pl % tfold) * Si;
+            L.i[cls][k] = idx[(long)pl * So + o];
             L.v[cls][k] = dy[(long)n * dy_nstride + (long)c * So + o];
           }
         }
@@ -263,7 +266,7 @@ __device__ __forceinline__ void class_apply(const ClassLoads<PT, PH, PW, KQ>& L,
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the loads stay in flight
 #pragma unroll
     for (int k = 0; k < KQ; ++k)
-      if (L.i[cls][k] >= 0) tile[L.i[cls][k]] += L.v[cls][k];
+      if (L.i[cls][k] >= 0) tile[L.b[cls][k] + L.i[cls][k]] += L.v[cls][k];
   }
 }
 
