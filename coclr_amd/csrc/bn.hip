@@ -84,20 +84,34 @@ bn_act_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale
     float* zp = z + (long)n * z_nstride + (long)c * S;
     const float* rp = res ? res + (long)n * res_nstride + (long)c * S : nullptr;
     if (VEC) {
-      const int S4 = S >> 2;
-      for (int i = blockIdx.x * 256 + threadIdx.x; i < S4; i += gridDim.x * 256) {
-        float4 v = reinterpret_cast<const float4*>(yp)[i];
-        v.x = fmaf(v.x, sc, sf); v.y = fmaf(v.y, sc, sf);
-        v.z = fmaf(v.z, sc, sf); v.w = fmaf(v.w, sc, sf);
-        if (rp) {
-          const float4 r = reinterpret_cast<const float4*>(rp)[i];
-          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      // four independent 16-byte loads per thread and trip: one load in flight per wave is ~32 KB per CU, short
+      // of what 8 TB/s needs at the loaded latency
+      const int S4 = S >> 2, stride = gridDim.x * 256;
+      for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < S4; i0 += 4 * stride) {
+        float4 v[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * stride;
+          if (i < S4) {
+            v[k] = reinterpret_cast<const float4*>(yp)[i];
+            if (rp) r[k] = reinterpret_cast<const float4*>(rp)[i];
+          }
         }
-        if (relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * stride;
+          if (i < S4) {
+            float4 w = v[k];
+            w.x = fmaf(w.x, sc, sf); w.y = fmaf(w.y, sc, sf);
+            w.z = fmaf(w.z, sc, sf); w.w = fmaf(w.w, sc, sf);
+            if (rp) { w.x += r[k].x; w.y += r[k].y; w.z += r[k].z; w.w += r[k].w; }
+            if (relu) {
+              w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f);
+              w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
+            }
+            reinterpret_cast<float4*>(zp)[i] = w;
+          }
         }
-        reinterpret_cast<float4*>(zp)[i] = v;
       }
     } else {
       for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
