@@ -638,7 +638,8 @@ def test_conv_temporal_winograd(case):
 
 WINO_HW_CASES = [(2, 64, 192, (2, 32, 32)), (2, 192, 208, (4, 16, 16)), (3, 48, 96, (3, 8, 8)),
                  (2, 32, 24, (5, 4, 4)), (2, 16, 48, (1, 6, 10)), (5, 160, 320, (2, 8, 8)),
-                 (2, 24, 64, (2, 12, 20)), (9, 40, 64, (3, 4, 4))]
+                 (2, 24, 64, (2, 12, 20)), (9, 40, 64, (3, 4, 4)),
+                 (33, 64, 64, (2, 16, 16))]            # more tiles than persistent workgroups: the tile loop
 
 
 @pytest.mark.parametrize("waves", ["two_per_simd", "one_per_simd"])
