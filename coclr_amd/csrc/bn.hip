@@ -146,23 +146,39 @@ bn_act_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__
     float ag = 0.f, agx = 0.f;
     if (VEC) {
       const int S4 = S >> 2;
-      for (int i = threadIdx.x; i < S4; i += 256) {
-        const float4 d = reinterpret_cast<const float4*>(dzp)[i];
-        const float4 v = reinterpret_cast<const float4*>(yp)[i];
-        float g0 = d.x, g1 = d.y, g2 = d.z, g3 = d.w;
-        if (relu) {
-          if (zp) {
-            const float4 zz = reinterpret_cast<const float4*>(zp)[i];
-            g0 = zz.x > 0.f ? g0 : 0.f; g1 = zz.y > 0.f ? g1 : 0.f;
-            g2 = zz.z > 0.f ? g2 : 0.f; g3 = zz.w > 0.f ? g3 : 0.f;
-          } else {
-            g0 = fmaf(v.x, sc, sf) > 0.f ? g0 : 0.f; g1 = fmaf(v.y, sc, sf) > 0.f ? g1 : 0.f;
-            g2 = fmaf(v.z, sc, sf) > 0.f ? g2 : 0.f; g3 = fmaf(v.w, sc, sf) > 0.f ? g3 : 0.f;
+      // two (dz, y) pairs in flight per thread and trip; the accumulation order over i is unchanged
+      for (int i0 = threadIdx.x; i0 < S4; i0 += 512) {
+        float4 dd[2], vv[2], zq[2];
+        bool ok[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = i0 + k * 256;
+          ok[k] = i < S4;
+          if (ok[k]) {
+            dd[k] = reinterpret_cast<const float4*>(dzp)[i];
+            vv[k] = reinterpret_cast<const float4*>(yp)[i];
+            if (relu && zp) zq[k] = reinterpret_cast<const float4*>(zp)[i];
           }
         }
-        ag += (g0 + g1) + (g2 + g3);
-        agx += g0 * ((v.x - mu) * is) + g1 * ((v.y - mu) * is) + g2 * ((v.z - mu) * is) +
-               g3 * ((v.w - mu) * is);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (!ok[k]) continue;
+          const float4 d = dd[k], v = vv[k];
+          float g0 = d.x, g1 = d.y, g2 = d.z, g3 = d.w;
+          if (relu) {
+            if (zp) {
+              const float4 zz = zq[k];
+              g0 = zz.x > 0.f ? g0 : 0.f; g1 = zz.y > 0.f ? g1 : 0.f;
+              g2 = zz.z > 0.f ? g2 : 0.f; g3 = zz.w > 0.f ? g3 : 0.f;
+            } else {
+              g0 = fmaf(v.x, sc, sf) > 0.f ? g0 : 0.f; g1 = fmaf(v.y, sc, sf) > 0.f ? g1 : 0.f;
+              g2 = fmaf(v.z, sc, sf) > 0.f ? g2 : 0.f; g3 = fmaf(v.w, sc, sf) > 0.f ? g3 : 0.f;
+            }
+          }
+          ag += (g0 + g1) + (g2 + g3);
+          agx += g0 * ((v.x - mu) * is) + g1 * ((v.y - mu) * is) + g2 * ((v.z - mu) * is) +
+                 g3 * ((v.w - mu) * is);
+        }
       }
     } else {
       for (int i = threadIdx.x; i < S; i += 256) {
@@ -256,33 +272,50 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
     float* dyp = dy + (long)n * dy_nstride + (long)c * S;
     float* drp = dres ? dres + (long)n * dres_nstride + (long)c * S : nullptr;
     if (VEC) {
-      const int S4 = S >> 2;
-      for (int i = blockIdx.x * 256 + threadIdx.x; i < S4; i += gridDim.x * 256) {
-        const float4 d = reinterpret_cast<const float4*>(dzp)[i];
-        const float4 v = reinterpret_cast<const float4*>(yp)[i];
-        float4 g = d;
-        if (relu) {
-          if (zp) {
-            const float4 zz = reinterpret_cast<const float4*>(zp)[i];
-            g.x = zz.x > 0.f ? g.x : 0.f; g.y = zz.y > 0.f ? g.y : 0.f;
-            g.z = zz.z > 0.f ? g.z : 0.f; g.w = zz.w > 0.f ? g.w : 0.f;
-          } else {
-            g.x = fmaf(v.x, sc, sf) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, sc, sf) > 0.f ? g.y : 0.f;
-            g.z = fmaf(v.z, sc, sf) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, sc, sf) > 0.f ? g.w : 0.f;
+      const int S4 = S >> 2, stride = gridDim.x * 256;
+      // two (dz, y) pairs in flight per thread and trip
+      for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < S4; i0 += 2 * stride) {
+        float4 dd[2], vv[2], zq[2];
+        bool ok[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = i0 + k * stride;
+          ok[k] = i < S4;
+          if (ok[k]) {
+            dd[k] = reinterpret_cast<const float4*>(dzp)[i];
+            vv[k] = reinterpret_cast<const float4*>(yp)[i];
+            if (relu && zp) zq[k] = reinterpret_cast<const float4*>(zp)[i];
           }
         }
-        if (drp) {
-          float4 r = g;
-          if (dres_accumulate) {
-            const float4 o = reinterpret_cast<const float4*>(drp)[i];
-            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (!ok[k]) continue;
+          const int i = i0 + k * stride;
+          const float4 v = vv[k];
+          float4 g = dd[k];
+          if (relu) {
+            if (zp) {
+              const float4 zz = zq[k];
+              g.x = zz.x > 0.f ? g.x : 0.f; g.y = zz.y > 0.f ? g.y : 0.f;
+              g.z = zz.z > 0.f ? g.z : 0.f; g.w = zz.w > 0.f ? g.w : 0.f;
+            } else {
+              g.x = fmaf(v.x, sc, sf) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, sc, sf) > 0.f ? g.y : 0.f;
+              g.z = fmaf(v.z, sc, sf) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, sc, sf) > 0.f ? g.w : 0.f;
+            }
           }
-          reinterpret_cast<float4*>(drp)[i] = r;
+          if (drp) {
+            float4 r = g;
+            if (dres_accumulate) {
+              const float4 o = reinterpret_cast<const float4*>(drp)[i];
+              r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+            }
+            reinterpret_cast<float4*>(drp)[i] = r;
+          }
+          float4 o;
+          o.x = fmaf(A, g.x, fmaf(B, v.x, D)); o.y = fmaf(A, g.y, fmaf(B, v.y, D));
+          o.z = fmaf(A, g.z, fmaf(B, v.z, D)); o.w = fmaf(A, g.w, fmaf(B, v.w, D));
+          reinterpret_cast<float4*>(dyp)[i] = o;
         }
-        float4 o;
-        o.x = fmaf(A, g.x, fmaf(B, v.x, D)); o.y = fmaf(A, g.y, fmaf(B, v.y, D));
-        o.z = fmaf(A, g.z, fmaf(B, v.z, D)); o.w = fmaf(A, g.w, fmaf(B, v.w, D));
-        reinterpret_cast<float4*>(dyp)[i] = o;
       }
     } else {
       for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
