@@ -273,7 +273,7 @@ def test_gradients_are_written_into_ddp_buckets(fake, monkeypatch):
             opt = torch.optim.Adam([{"params": p} for _, p in ddp.named_parameters()], lr=1e-3,
                                    weight_decay=1e-5)
             ddp.train()
-            aliased = []
+            aliased, verified = [], []
             for step in range(4):
                 g = torch.Generator().manual_seed(50 + step)
                 block = torch.randn(4, 2, 3, 8, 32, 32, generator=g)
@@ -290,7 +290,10 @@ def test_gradients_are_written_into_ddp_buckets(fake, monkeypatch):
                             p.grad.data_ptr() == s[1].data_ptr():
                         n += 1
                 aliased.append(n)
+                verified.append(sum(1 for p in model.encoder_q[0].parameters()
+                                    if id(p) in engine._SLOTS_VERIFIED))
                 opt.step()
+            run.verified = verified
             return [p.detach().clone() for p in model.parameters()], aliased, (model, ddp)
 
         ref, _, _ = run(False)
@@ -302,6 +305,14 @@ def test_gradients_are_written_into_ddp_buckets(fake, monkeypatch):
         assert aliased[-1] == nparams and aliased[-2] == nparams, (aliased, nparams)
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+        # ... and a view counts as ACCEPTED by DDP (engine._SLOTS_VERIFIED: what an un-joined weight-gradient
+        # stream requires, engine.Run.defer_side) only after a whole pass in which the bucket stayed at the
+        # published address and every gradient in it was the alias: step 0 publishes, step 1 re-publishes the
+        # rebuilt buckets (which un-verifies), step 2 is the first such pass
+        assert run.verified[0] == 0 and run.verified[1] == 0 and run.verified[2] == nparams, run.verified
+        p0 = next(model.encoder_q[0].parameters())
+        engine.set_grad_slot(p0, engine._GRAD_SLOTS[id(p0)][1])          # a re-publication un-verifies
+        assert id(p0) not in engine._SLOTS_VERIFIED
         # a caller that keeps `.grad` (zero_grad(set_to_none=False)) must NOT get the in-place path
         run_ = engine.Run(torch.device("cpu"), save=True)
         p = next(model.encoder_q[0].parameters())
