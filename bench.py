@@ -35,6 +35,16 @@ Legs (all in the one JSON line):
   roofline_nce    the q.queue^T logits GEMM at K=16384: bytes and FLOPs / time, MFMA-busy from the
                   PMC pass committed under profiles/
   cpu_baseline    the CPU oracle (port of the reference step) on this host's cores, N=1 only
+  self_check      one steady-state step run twice from the same snapshot -- as timed, and SERIAL (joins not
+                  deferred, DDP's own bucket copies, all-gather exchange, no graph replay, one stream) --
+                  with everything the step changes required to be bit-identical (bench_multi.py)
+  value_k16384    N=1 only: the same step on moco-k=16384, the queue size every N > 1 run uses, so that
+                  value(N) / value_k16384 is BASELINE config 3 over config 3
+
+At world > 1 the ranks the driver starts are SUPERVISORS (bench_multi.supervise): each runs the measuring
+process as a child; a child that hangs, dies or raises is replaced by one further down the degradation
+ladder (bench_multi.RUNG_NAMES) and rank 0 still prints ONE valid JSON line, `multi_gpu.rung` naming what
+had to be switched off and `multi_gpu.attempts` what was tried.
 """
 import argparse
 import json
@@ -72,7 +82,9 @@ def parse():
                     help="launch-contract rehearsal on the host (gloo, tiny shapes): only valid when "
                          "the caller has replaced coclr_amd.ops by the tests' ATen double "
                          "(tests/bench_dryrun.py); never a measurement")
-    ap.add_argument("--hang-timeout", type=float, default=240.0,
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="skip the fast-vs-serial bit-identity check of one step (bench_multi.SelfCheck)")
+    ap.add_argument("--hang-timeout", type=float, default=150.0,
                     help="world > 1: seconds without progress (no new collective, no new step) after "
                          "which a rank reports the exchange it is stuck in and the job ends")
     ap.add_argument("--one-gpu-rehearsal", action="store_true",
@@ -156,17 +168,27 @@ class Watchdog:
         self.parallel = parallel
         self.phase = ["start", 0]
         self.done = False
+        # set once the timed region has been measured: a hang in an OPTIONAL leg after it (host floor at
+        # world > 1) must not cost the record -- the watchdog prints it and ends the job successfully
+        self.complete_record = None       # rank 0: the record itself
+        self.record_complete = False      # every rank: the timed region has been measured
+        self.optional = False
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
-    def at(self, what):
+    def at(self, what, optional=False):
         self.phase[0], self.phase[1] = what, self.phase[1] + 1
+        self.optional = optional
 
     def _run(self):
+        import bench_multi
         seen, since = None, time.monotonic()
         while not self.done:
             time.sleep(min(1.0, self.limit / 4))
             cur = (self.phase[1], self.parallel.LAST[2])
+            # what the supervisor reads if this process dies without a word (bench_multi.supervise)
+            bench_multi.write_status(phase=self.phase[0], last_collective=self.parallel.LAST[0],
+                                     collectives_issued=self.parallel.LAST[2])
             if cur != seen:
                 seen, since = cur, time.monotonic()
                 continue
@@ -176,6 +198,12 @@ class Watchdog:
                     "phase": self.phase[0], "last_collective": self.parallel.LAST[0],
                     "collectives_issued": self.parallel.LAST[2]}
             print("bench watchdog: " + json.dumps(diag), file=sys.stderr, flush=True)
+            bench_multi.write_status(**diag)
+            if self.optional and self.record_complete:
+                if self.rank == 0 and self.complete_record is not None:
+                    rec = dict(self.complete_record, optional_leg_hung=diag)
+                    print(json.dumps(rec), flush=True)
+                os._exit(0)
             if self.rank == 0:
                 rec = dict(self.base, value=None, ms_per_step=None, hang=diag)
                 print(json.dumps(rec), flush=True)
@@ -221,12 +249,21 @@ def cross_rank_check(model, out, device, world):
     finite = torch.tensor([1.0 if bool(torch.isfinite(out).all()) else 0.0], device=device)
     dist.all_reduce(finite, op=dist.ReduceOp.MIN)
     worst, where = 0.0, None
+    all_finite = bool(torch.isfinite(torch.stack(got)).all())
+    identical = all_finite
     for r in range(1, world):
-        d = (got[r] - got[0]).abs()
-        if float(d.max()) > worst:
-            worst = float(d.max())
-            where = "%s on rank %d" % (names[int(d.argmax()) // 2], r)
-    return {"replicas_identical": worst == 0.0, "max_abs_digest_diff": worst, "first_mismatch": where,
+        if not torch.equal(got[r], got[0]):
+            identical = False
+            d = (got[r] - got[0]).abs()
+            d = torch.where(torch.isfinite(d), d, torch.full_like(d, float("inf")))
+            if where is None or float(d.max()) > worst:
+                worst = float(d.max())
+                where = "%s on rank %d" % (names[int(d.argmax()) // 2], r)
+    if not all_finite and where is None:
+        bad = (~torch.isfinite(torch.stack(got))).nonzero()[0]
+        where = "%s on rank %d (not finite)" % (names[int(bad[1]) // 2], int(bad[0]))
+    return {"replicas_identical": identical, "digests_finite": all_finite, "max_abs_digest_diff": worst,
+            "first_mismatch": where,
             "fields": names, "logits_finite_on_every_rank": bool(finite.item() == 1.0),
             "what": "after one full step (fwd, loss, bwd, all-reduce, Adam, momentum, enqueue): float64 "
                     "digests (sum and position-weighted sum) of the queue(s), the pointer and the "
@@ -309,42 +346,83 @@ def nce_roofline(device, B):
     return rec
 
 
+def dominant_kernel_name(algo):
+    """The kernel the library selects for Conv_2c.conv1's forward at the bench shape (the selection of
+    csrc/conv_igemm.hip `case 60`, restated: the choice depends on the geometry's algorithm and on two
+    A/B switches read per call)."""
+    if algo != 1:
+        return "conv_igemm_kernel<1,3,3> direct implicit GEMM"
+    x16 = os.environ.get("COCLR_WINO_X16", "1") != "0"
+    w8 = os.environ.get("COCLR_WINO_W8", "1")[:1] != "0"
+    if x16 and w8:
+        return "conv_wino_hw8_kernel<8,3> Winograd F(2x2,3x3), two waves per SIMD, 16-byte window DMA"
+    if x16:
+        return "conv_wino_hw_kernel<8,3,true> Winograd F(2x2,3x3), one wave per SIMD, 16-byte window DMA"
+    return "conv_wino_hw_kernel<8,6|10> Winograd F(2x2,3x3), 4-byte window DMA"
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
+    if world > 1 and os.environ.get("COCLR_BENCH_CHILD") != "1" and \
+            os.environ.get("COCLR_BENCH_LADDER", "1") != "0":
+        # the ranks the driver starts supervise; the measuring processes are their children
+        import bench_multi
+        sys.exit(bench_multi.supervise(sys.argv[1:], args.hang_timeout))
+    try:
+        measure(args, world)
+    except SystemExit:
+        raise
+    except BaseException as e:
+        if world > 1:
+            import traceback
+            import bench_multi
+            from coclr_amd import parallel as _par
+            bench_multi.write_status(error=("%s: %s" % (type(e).__name__, e))[:600],
+                                     last_collective=_par.LAST[0], collectives_issued=_par.LAST[2],
+                                     phase=(_DOG[0].phase[0] if _DOG[0] is not None else "start"))
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(1)              # peers are waiting in a collective this rank will never enter
+        raise
+
+
+_DOG = [None]
+
+
+def measure(args, world):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dry = args.dry_run_host
+    import datetime
+    init = {"rank": rank, "world_size": world,
+            "timeout": datetime.timedelta(seconds=max(60.0, 2 * args.hang_timeout))}
+    if os.environ.get("COCLR_BENCH_INIT"):
+        init["init_method"] = os.environ["COCLR_BENCH_INIT"]     # a child's own rendezvous (bench_multi)
     if dry:
         from coclr_amd import ops as _ops
         if _ops.conv_fwd.__module__ == "coclr_amd.ops":
             raise SystemExit("--dry-run-host needs the tests' double (python tests/bench_dryrun.py)")
         device = torch.device("cpu")
-        import datetime
-        dist.init_process_group("gloo", rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=max(60.0, 2 * args.hang_timeout)))
+        dist.init_process_group("gloo", **init)
         torch.cuda.synchronize = lambda *a, **k: None
         args.no_extra_legs = args.no_cpu_baseline = True
     elif args.one_gpu_rehearsal:
         local_rank = 0
         torch.cuda.set_device(0)
         device = torch.device("cuda", 0)
-        import datetime
-        dist.init_process_group("gloo", rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=max(60.0, 2 * args.hang_timeout)))
+        dist.init_process_group("gloo", **init)
         args.no_extra_legs = args.no_cpu_baseline = True
     else:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-        import datetime
         # RCCL's own watchdog fires after the bench's (which names the call site first)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device,
-                                timeout=datetime.timedelta(seconds=max(60.0, 2 * args.hang_timeout)))
+        dist.init_process_group("nccl", device_id=device, **init)
         if world > 1:
             # the comparison legs (caller's optimiser, unmodified loop, isolated rooflines) are
             # single-GPU measurements; a scaling run reports `value` and nothing that could fail beside it
@@ -354,35 +432,70 @@ def main():
     _lib.load()                      # fail loudly if the HIP library is missing
     from model.pretrain import InfoNCE, CoCLR         # the shim also resolves torch.optim.Adam
     from coclr_amd import loss as L, ops, engine
+    from coclr_amd import parallel as _par
+    import coclr_amd.model.pretrain as _impl
     from coclr_amd.optim import Adam as NativeAdam, _TorchAdam
+    import bench_multi
+    if os.environ.get("COCLR_BENCH_FAULT"):
+        bench_multi.inject_fault(os.environ["COCLR_BENCH_FAULT"], rank)      # tests only
 
+    # N > 1: the K400 queue of BASELINE configs[2]; N = 1: configs[1] (the metric's own configuration) as
+    # `value`, and the N > 1 queue as the extra leg `value_k16384`
     K = args.moco_k or (2048 if world == 1 else 16384)
     B = args.batch
     dog = None
     if world > 1:
-        dog = Watchdog(rank, world, args.hang_timeout, {
+        dog = _DOG[0] = Watchdog(rank, world, args.hang_timeout, {
             "metric": "clips/sec (whole node)", "unit": "clips/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic"})
-    torch.manual_seed(0)
-    if args.model == "infonce":
-        model = InfoNCE(args.net, 128, K, 0.999, 0.07)
-    else:
-        model = CoCLR(args.net, 128, K, 0.999, 0.07, topk=5)
-        model.queue_label.fill_(1)       # queue "full": cross-modal mining active
-        model.queue_vname.copy_(torch.randint(0, 2 ** 31, (K,)))
-        model.queue_is_full = True
-    if dry:
-        ddp = nn.parallel.DistributedDataParallel(model)
-    else:
-        model = model.cuda(local_rank)
-        ddp = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])   # main_nce.py:172
+
+    def build(K_):
+        torch.manual_seed(0)
+        if args.model == "infonce":
+            m = InfoNCE(args.net, 128, K_, 0.999, 0.07)
+        else:
+            m = CoCLR(args.net, 128, K_, 0.999, 0.07, topk=5)
+            m.queue_label.fill_(1)       # queue "full": cross-modal mining active
+            m.queue_vname.copy_(torch.randint(0, 2 ** 31, (K_,)))
+            m.queue_is_full = True
+        return m if dry else m.cuda(local_rank)
+
+    def wrap(m, hook=True):
+        # main_nce.py:172; `hook=False` is the wrapper of the serial reference / of rungs >= 2
+        saved = os.environ.get("COCLR_DDP_HOOK")
+        if not hook:
+            os.environ["COCLR_DDP_HOOK"] = "0"
+        try:
+            if dry:
+                return nn.parallel.DistributedDataParallel(m)
+            return nn.parallel.DistributedDataParallel(m, device_ids=[local_rank])
+        finally:
+            if not hook:
+                if saved is None:
+                    os.environ.pop("COCLR_DDP_HOOK", None)
+                else:
+                    os.environ["COCLR_DDP_HOOK"] = saved
+
+    switches = bench_multi.Switches()
+    rung = int(os.environ.get("COCLR_BENCH_RUNG", "0"))
+    switches.apply(rung)
+    model = build(K)
+    wrappers = {}
+
+    def make_ddp(hook):
+        hook = bool(hook)
+        if hook not in wrappers:
+            wrappers[hook] = wrap(model, hook)
+            wrappers[hook].train()
+        return wrappers[hook]
+
+    ddp = make_ddp(switches.wants_hook(rung))
     # main_nce.py:190-200: one param group per tensor, frozen ones included
     groups = [{"params": p} for _, p in ddp.named_parameters()]
     opt = torch.optim.Adam(groups, lr=1e-3, weight_decay=1e-5)
     assert isinstance(opt, NativeAdam), "the model.pretrain shim should have resolved torch.optim.Adam"
     criterion = L.CrossEntropyLoss()
-    ddp.train()
     if args.model == "coclr":
         model.sampler.eval()
 
@@ -404,14 +517,16 @@ def main():
                    lambda y, *a, **kw: tuple(y.shape) == (B, 64, th, hh, hh))
 
     acc = {}
-
     torch_ce = nn.CrossEntropyLoss().cuda(local_rank) if not dry else nn.CrossEntropyLoss()
     meters = {}
+    live = {"ddp": ddp, "opt": opt, "pool": pool}
 
-    def step(i, native=True):
-        blocks = pool[i % 2]
+    def step(i, native=True, on=None):
+        net = on if on is not None else live["ddp"]
+        cur = live["opt"]
+        blocks = live["pool"][i % 2]
         if args.model == "infonce":
-            out, tgt = ddp(blocks[0])
+            out, tgt = net(blocks[0])
             if native == "unmodified":
                 # main_nce.py:313-327 verbatim: criterion, accuracy helper, three host reads
                 loss = torch_ce(out, tgt)
@@ -423,7 +538,7 @@ def main():
             else:
                 loss = nn.functional.cross_entropy(out, tgt)
         else:
-            out, mask = ddp(blocks[0], blocks[1], vsrc)
+            out, mask = net(blocks[0], blocks[1], vsrc[:blocks[0].shape[0]])
             if native:
                 loss = L.multi_nce_loss(out, mask, drop_self=True)
                 acc["top1"], acc["top5"] = L.calc_mask_accuracy(out, mask, (1, 5))
@@ -436,6 +551,7 @@ def main():
         return loss
 
     def timed_run(nsteps, native):
+        assert _par.TIMINGS is None, "instrumented (serialising) collectives must be off in a timed region"
         dist.barrier()
         torch.cuda.synchronize()
         calls0 = _lib.CALLS[0]
@@ -451,16 +567,49 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax), t_host, (_lib.CALLS[0] - calls0) / nsteps, float(loss.detach())
 
-    cur = opt
+    def small_batch_floor(nf=12):
+        """the same step on 4 clips per GPU, where the GPU is never the bottleneck: 4 + nf small steps in all
+        put the queue pointer back on the big batch's grid (16 x 4 = 2 x 32 clips per rank)"""
+        small = [[blk[:4].contiguous() for blk in blks] for blks in pool]
+        live["pool"] = small
+        try:
+            for i in range(4):
+                step(i)
+            dtf, _, _, _ = timed_run(nf, True)
+        finally:
+            live["pool"] = pool
+        step(0)                              # back to the benchmark shape (graphs are kept per shape)
+        return round(dtf / nf * 1e3, 2)
+
+    # ---- first contact and self-check -------------------------------------------------------------------
     multi = None
-    if world > 1:
-        # ---- first contact: one CHECKED step, then two instrumented ones (per-collective wall time) ----
-        from coclr_amd import parallel as _par
-        import coclr_amd.model.pretrain as _impl
-        dog.at("checked step (first forward: buffer broadcast, gloo side group, shuffle exchange)")
-        step(0)
+    self_check = None
+    check = None
+    npre = 4       # bucket views published (1), verified (2), joins deferred from (3): 4 is a steady-state step
+    if dog is not None:
+        dog.at("first steps (buffer broadcast, gloo side group, peer mapping, exchange scheme chosen, "
+               "graph capture, bucket views published and verified)")
+    if world > 1 or not args.no_self_check:
+        for i in range(npre):
+            step(i)
         torch.cuda.synchronize()
+    if world > 1:
         check = cross_rank_check(model, acc["logits"], device, world)
+        if not check["replicas_identical"] or not check["logits_finite_on_every_rank"]:
+            print("bench: cross-rank check FAILED: %s" % json.dumps(check), file=sys.stderr, flush=True)
+    if not args.no_self_check:
+        sc = bench_multi.SelfCheck(model, opt, make_ddp, lambda net, i: step(i, on=net), device, switches,
+                                   torch.cuda.synchronize)
+        self_check, rung = sc.run(rung, batch=npre, dog=dog)
+        live["ddp"] = make_ddp(switches.wants_hook(rung))
+        if not self_check["passed"]:
+            print("bench: self-check FAILED on every rung: %s" % json.dumps(self_check["trials"]),
+                  file=sys.stderr, flush=True)
+        # the hooked wrapper publishes its bucket views again (the serial run took the engine's slots):
+        # three steps until joins are deferred again, whatever --warmup says
+        for i in range(3):
+            step(i)
+    if world > 1:
         dog.at("instrumented steps (collectives serialised and timed one by one)")
         _par.TIMINGS = []
         ninst = 2
@@ -476,25 +625,32 @@ def main():
         coll = [{"collective": name, "calls_per_step": round(a[0] / ninst, 2),
                  "ms_per_call": round(a[1] / a[0], 3), "mbytes": round(a[2] / 1e6, 3),
                  "gbs": round(a[2] / 1e6 / max(a[1] / a[0], 1e-6), 2)} for name, a in agg.items()]
-        multi = {"rccl_ranks": world if not dry else 0, "backend": dist.get_backend(),
-                 "shuffle_mode": _impl._SHUFFLE_MODE,
+        shuffle_ms = sum(a[1] / ninst for name, a in agg.items()
+                         if "_shuffle" in name or "all_to_all" in name or "parked" in name
+                         or ("all_gather_into_tensor" in name and a[2] > (1 << 20)))
+        multi = {"rccl_ranks": world if not (dry or args.one_gpu_rehearsal) else 0,
+                 "backend": dist.get_backend(),
+                 "rung": rung, "rung_name": bench_multi.RUNG_NAMES[rung],
+                 "rung_what": bench_multi.RUNG_WHAT[rung], "switches": switches.describe(),
+                 "shuffle_mode": _impl._SHUFFLE_MODE, "shuffle_selection": dict(_impl._SHUFFLE_INFO),
+                 "shuffle_exchange_ms_per_step_serialised": round(shuffle_ms, 3),
                  "split_stages": True, "cross_rank": check, "collectives": coll,
                  "collectives_ms_per_step_serialised": round(sum(a[1] for a in agg.values()) / ninst, 3),
                  "collectives_note": "each call bracketed by device synchronisations in two extra, untimed "
                                      "steps: its cost if nothing overlapped it, INCLUDING the wait for the "
                                      "slowest rank to arrive; the timed steps run them asynchronously"}
-        if not check["replicas_identical"] or not check["logits_finite_on_every_rank"]:
-            print("bench: cross-rank check FAILED: %s" % json.dumps(check), file=sys.stderr, flush=True)
     if dog is not None:
         dog.at("warm-up steps")
     for i in range(args.warmup):
         step(i)
     if dog is not None:
         dog.at("timed steps")
+    deferred0 = engine.DEFERRED[0]
     timer.enabled = not dry
     dt, t_host, calls_per_step, final_loss = timed_run(args.steps, True)
     timer.enabled = False
-    assert dry or opt._plan is not None, "the single-launch Adam did not run"
+    deferred_per_step = (engine.DEFERRED[0] - deferred0) / max(1, args.steps)
+    assert dry or live["opt"]._plan is not None, "the single-launch Adam did not run"
     # a number measured on a broken kernel is worse than no number
     if not (final_loss == final_loss and abs(final_loss) < 1e6):
         raise SystemExit("bench: the loss after the timed steps is %r -- refusing to report a throughput"
@@ -503,7 +659,7 @@ def main():
     # ---- the same step as an unpatched caller gets it: torch's own Adam over the 470 groups ----------
     caller = None
     if not args.no_extra_legs:
-        cur = _TorchAdam(groups, lr=1e-3, weight_decay=1e-5)
+        live["opt"] = _TorchAdam(groups, lr=1e-3, weight_decay=1e-5)
         for i in range(2):
             step(i, native=False)
         n2 = max(3, min(args.steps, 10))
@@ -512,10 +668,11 @@ def main():
                   "steps": n2, "host_enqueue_ms_per_step": round(t_host2 / n2 * 1e3, 2),
                   "what": "torch.optim.Adam (torch's implementation) over %d single-tensor groups + "
                           "nn.functional.cross_entropy, everything else identical" % len(groups)}
-        cur = opt
+        live["opt"] = opt
 
     # ---- the unmodified script's iteration, and the world>1 autograd structure --------------------------
     unmodified = split = None
+    host_floor_split = None
     if not args.no_extra_legs and args.model == "infonce":
         for i in range(2):
             step(i, native="unmodified")
@@ -523,41 +680,59 @@ def main():
         dt3, t_host3, _, _ = timed_run(n3, "unmodified")
         unmodified = {"value": round(B * world * n3 / dt3, 2), "ms_per_step": round(dt3 / n3 * 1e3, 3),
                       "steps": n3,
-                      "what": "main_nce.py:307-331 as written: the shim-resolved torch.optim.Adam, "
-                              "nn.CrossEntropyLoss, utils.calc_topk_accuracy (ATen top-k over the "
+                      "what": "THE NORTH STAR'S DROP-IN NUMBER: main_nce.py:307-331 exactly as written, not a "
+                              "line of the caller edited -- the shim-resolved torch.optim.Adam, the script's "
+                              "own nn.CrossEntropyLoss, utils.calc_topk_accuracy (ATen top-k over the "
                               "logits), top1.item() / top5.item() / loss.item() every iteration"}
         if args.net in ("s3d", "s3dg") and world == 1:
             from coclr_amd.backbone import s3dg as _s3dg
             saved_mode = _s3dg._SPLIT_MODE
             _s3dg._SPLIT_MODE = "1"
             try:
-                for i in range(2):
+                for i in range(4):
                     step(i)
                 dt4, _, _, _ = timed_run(n3, True)
+                if B >= 16:
+                    host_floor_split = small_batch_floor()
             finally:
                 _s3dg._SPLIT_MODE = saved_mode
             split = {"value": round(B * world * n3 / dt4, 2), "ms_per_step": round(dt4 / n3 * 1e3, 3),
-                     "steps": n3,
+                     "steps": n3, "host_floor_ms_per_step": host_floor_split,
                      "what": "`value` with one autograd node per backbone stage (COCLR_SPLIT_STAGES=1), "
-                             "the structure used at world > 1"}
+                             "the structure used at world > 1; host_floor_ms_per_step = that structure on "
+                             "4 clips per GPU (only the host paces it)"}
             step(0)
 
     # ---- host floor: the same step on 4 clips per GPU, where the GPU is never the bottleneck -----------
     host_floor = None
     if not args.no_extra_legs and args.model == "infonce" and B >= 16:
-        small = [[blk[:4].contiguous() for blk in blks] for blks in pool]
-        big_pool, pool = pool, small
+        host_floor = small_batch_floor()
+
+    # ---- N = 1: the queue size of every N > 1 run, so that value(N) / value_k16384 compares like with like
+    k16 = None
+    if world == 1 and not args.no_extra_legs and K != 16384 and args.moco_k is None:
+        model16 = build(16384)
+        ddp16 = wrap(model16)
+        ddp16.train()
+        opt16 = torch.optim.Adam([{"params": p} for _, p in ddp16.named_parameters()], lr=1e-3,
+                                 weight_decay=1e-5)
+        live["ddp"], live["opt"] = ddp16, opt16
         for i in range(4):
             step(i)
-        nf = 12           # 16 small steps in all: the queue pointer is back on the big batch's grid
-        dtf, _, _, _ = timed_run(nf, True)
-        host_floor = round(dtf / nf * 1e3, 2)
-        pool = big_pool
-        step(0)                                   # back to the benchmark shape (graphs are kept per shape)
+        n5 = max(5, min(args.steps, 20))
+        dt5, _, _, _ = timed_run(n5, True)
+        k16 = {"value": round(B * world * n5 / dt5, 2), "ms_per_step": round(dt5 / n5 * 1e3, 3), "steps": n5,
+               "what": "the same step with moco-k=16384 (BASELINE configs[2]'s queue, what bench.py runs at "
+                       "every N > 1): the N=1 point of the scaling curve on the SAME configuration"}
+        live["ddp"], live["opt"] = make_ddp(switches.wants_hook(rung)), opt
+        del model16, ddp16, opt16
 
     # ---- isolated micro-runs on rank 0: the dominant kernel, the largest BN apply, the NCE GEMM ------
     iso_ms = bn_iso_ms = None
     nce = None
+    dom_algo = None
+    if rank == 0 and args.net == "s3d" and not dry:
+        dom_algo = ops.conv_geom(B, 64, 192, (tq, hq, hq), (1, 3, 3), (1, 1, 1), (0, 1, 1)).algo
     if rank == 0 and args.net == "s3d" and not args.no_extra_legs:
         g = ops.conv_geom(B, 64, 192, (tq, hq, hq), (1, 3, 3), (1, 1, 1), (0, 1, 1))   # as the model
         run = engine.Run(device, save=False)
@@ -575,37 +750,38 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         iso_ms = e0.elapsed_time(e1) / 20
-        assert g.algo == 1
         del xi, wi, yi, sti
         yb = torch.randn(B, 64, th, hh, hh, device=device)
         zb = torch.empty_like(yb)
-        sc = torch.rand(2, 64, device=device) + 0.5
+        sc_ = torch.rand(2, 64, device=device) + 0.5
         for _ in range(3):
-            ops.bn_act_apply(yb, sc[0], sc[1], None, zb, True)
+            ops.bn_act_apply(yb, sc_[0], sc_[1], None, zb, True)
         e0.record()
         for _ in range(20):
-            ops.bn_act_apply(yb, sc[0], sc[1], None, zb, True)
+            ops.bn_act_apply(yb, sc_[0], sc_[1], None, zb, True)
         e1.record()
         torch.cuda.synchronize()
         bn_iso_ms = e0.elapsed_time(e1) / 20
         del yb, zb
         nce = nce_roofline(device, B)
 
+    rec = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         clips = B * world * args.steps / dt
         kms, nk = timer.mean_ms("dominant")
         flops = 2.0 * B * 192 * 64 * 9 * tq * hq * hq          # direct-convolution FLOPs per launch
-        issued = flops * 16.0 / 36.0                             # F(2x2,3x3): 16 of 36 products
+        wino = dom_algo == 1
+        issued = flops * 16.0 / 36.0 if wino else flops         # F(2x2,3x3): 16 of 36 products
         roof = None
         traffic = None
         tpath = next((t for t in (os.path.join(ROOT, "profiles", tag + "_traffic.json")
-                                  for tag in ("r04", "r03", "r02")) if os.path.exists(t)), "")
+                                  for tag in ("r05", "r04", "r03", "r02")) if os.path.exists(t)), "")
         if os.path.exists(tpath) and args.net == "s3d" and B == 32:
             # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
             # (counters cannot be read from inside the process)
             tj = json.load(open(tpath))
-            if "wino" in tj["kernel"]:
+            if ("wino" in tj["kernel"]) == wino:
                 traffic = {"bytes_per_launch": tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"],
                            "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
                            "source": tj["source"]}
@@ -614,14 +790,14 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic,
-                    "kernel": "conv_wino_hw8_kernel<8,3> Winograd F(2x2,3x3), two waves per SIMD, 16-byte "
-                              "window DMA (Conv_2c.conv1 64->192, "
-                              "%dx%dx%d, N=%d; the query encoder's forward launches inside the timed "
-                              "steps, sharing the chip with the key-encoder stream)" % (tq, hq, hq, B),
+                    "kernel": "%s (Conv_2c.conv1 64->192, %dx%dx%d, N=%d; the query encoder's forward "
+                              "launches inside the timed steps, sharing the chip with the key-encoder "
+                              "stream)" % (dominant_kernel_name(dom_algo), tq, hq, hq, B),
                     "launches_timed": nk, "avg_launch_ms": round(kms, 4),
                     "mfma_gflop_per_launch": round(issued / 1e9, 2),
-                    "what": "achieved = MFMA FLOPs the kernel actually issues (16 of the 36 products "
-                            "of the direct convolution) / average launch time",
+                    "what": "achieved = MFMA FLOPs the kernel actually issues (%s) / average launch time"
+                            % ("16 of the 36 products of the direct convolution" if wino else
+                               "the direct convolution's"),
                     "direct_equiv": {"algorithmic_gflop_per_launch": round(flops / 1e9, 2),
                                      "achieved": round(flops / (kms * 1e-3) / 1e12, 2),
                                      "frac": round(flops / (kms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}}
@@ -670,7 +846,9 @@ def main():
                      "REHEARSAL: every rank on ONE GPU over gloo (real kernels, not a measurement)"),
             "config": {"workload": "%s %s moco-k=%d seq_len=%d img=%d bs=%d/GPU, DDP(nccl=RCCL) x%d, "
                                    "fwd + loss + top-1/5 + bwd + Adam(lr 1e-3, wd 1e-5) over %d "
-                                   "single-tensor param groups (main_nce.py:190-200)"
+                                   "single-tensor param groups (main_nce.py:190-200); caller: "
+                                   "import-swapped loss + accuracy (INTEGRATION.md section 3), the literally "
+                                   "unmodified caller is value_unmodified_caller"
                                    % (args.net, args.model, K, args.seq_len, args.img_dim, B, world,
                                       len(groups)),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
@@ -680,7 +858,9 @@ def main():
                        "ddp": "DistributedDataParallel(model, device_ids=[gpu]) as main_nce.py:172; "
                               "gradient_as_bucket_view=%s (the shim's default for this model, "
                               "COCLR_PATCH_DDP=0 restores torch's False: about -3 %%)"
-                              % getattr(ddp, "gradient_as_bucket_view", None),
+                              % getattr(live["ddp"], "gradient_as_bucket_view", None),
+                       "scaling_note": "N > 1 runs moco-k=16384 (BASELINE configs[2]); the N=1 point on that "
+                                       "queue size is value_k16384 of the N=1 line",
                        "excluded_caller_work": "meters' .item() syncs, dataloader + H2D",
                        "final_loss": round(final_loss, 4)},
             "roofline": roof, "roofline_hbm": roof_hbm, "roofline_nce": nce,
@@ -691,7 +871,13 @@ def main():
                          "queue is full (no synchronising call inside a step, tools/find_syncs.py); "
                          "host_floor = the same step at 4 clips/GPU, where only the host paces it",
             "abi_calls_per_step": round(calls_per_step, 1),
+            "deferred_joins_per_step": round(deferred_per_step, 2),
+            "self_check": self_check,
         }
+        if self_check is not None and not self_check["passed"]:
+            rec["self_check_failed"] = True
+        if check is not None and not (check["replicas_identical"] and check["logits_finite_on_every_rank"]):
+            rec["cross_rank_failed"] = True
         if multi is not None:
             rec["multi_gpu"] = multi
         if unmodified is not None:
@@ -700,13 +886,28 @@ def main():
             rec["value_split_stages"] = split
         if caller is not None:
             rec["value_caller_optimizer"] = caller
+        if k16 is not None:
+            rec["value_k16384"] = k16
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)
+
+    # ---- N > 1: host floor of the per-stage structure; optional -- a hang here must not cost the record --
+    if world > 1 and args.model == "infonce" and B >= 16 and K % (4 * world) == 0:
+        dog.complete_record, dog.record_complete = rec, True
+        dog.at("host floor (4 clips per GPU) -- optional leg", optional=True)
+        try:
+            floor = small_batch_floor()
+            if rank == 0:
+                rec["multi_gpu"]["host_floor_ms_per_step"] = floor
+        except Exception as e:          # the record is complete without it
+            if rank == 0:
+                rec["multi_gpu"]["host_floor_error"] = ("%s: %s" % (type(e).__name__, e))[:300]
     if dog is not None:
-        dog.at("final barrier")
+        dog.at("final barrier", optional=True)
     dist.barrier()
     if dog is not None:
         dog.done = True
+    bench_multi.write_status(phase="done")
     dist.destroy_process_group()
     if rank == 0:
         # last thing on stdout (RCCL prints its banner lazily during the run)

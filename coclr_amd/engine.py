@@ -71,11 +71,39 @@ _SIDE = {}
 _PENDING_SIDE = {}    # device -> tensors read by weight-gradient kernels of nodes that deferred their join
 DEFER_JOIN = os.environ.get("COCLR_DEFER_JOIN", "1") != "0"
 DEFERRED = [0]        # nodes that left the stream un-joined (tests / bench read it)
+# id(param) -> event on the weight-gradient stream behind the last kernel that writes the parameter's
+# gradient in the current backward pass (one event per node that deferred its join), or None when the node
+# joined the stream on the main one.  Read -- and consumed -- by the bucket hook (coclr_amd/parallel.py).
+_SIDE_EVENTS = {}
+_CALLBACK_QUEUED = {}  # device -> an end-of-backward join has been queued for the running backward pass
 
 
 def side_stream_of(device):
     """The weight-gradient stream of `device`, if any work was ever put on it."""
     return _SIDE.get(device)
+
+
+def side_events_for(params):
+    """Events on the weight-gradient stream that the gradients of `params` are complete behind (duplicates
+    removed).  Parameters without an entry were not written by a node that deferred its join -- the
+    projection head (main stream), a node that joined, a graph replay (joins inside the graph): the main
+    stream orders them."""
+    evs = []
+    for p in params:
+        ev = _SIDE_EVENTS.pop(id(p), None)
+        if ev is not None and not any(ev is e for e in evs):
+            evs.append(ev)
+    return evs
+
+
+def _end_of_backward(device):
+    """Autograd end-of-pass callback queued by the first node that deferred its join: if the node that ran
+    LAST deferred as well (stage 1 frozen or not part of the graph), nobody has joined the weight-gradient
+    stream -- do it here, in front of the optimiser, and release what its kernels read."""
+    _CALLBACK_QUEUED[device] = False
+    pending = _PENDING_SIDE.pop(device, None)
+    if pending and device in _SIDE:
+        torch.cuda.current_stream(device).wait_stream(_SIDE[device])
 
 
 _SIDE_PRIORITY = int(os.environ.get("COCLR_WGRAD_PRIORITY", "0"))
@@ -448,6 +476,9 @@ class Run:
         if self._side_used or pending:
             torch.cuda.current_stream(self.device).wait_stream(_SIDE[self.device])
             self._side_used = False
+        if _SIDE_EVENTS:
+            for k in self.param_grads:
+                _SIDE_EVENTS.pop(k, None)         # ordered by the main stream from here on
         self._side_keep = []
         self._side_windows = []
 
@@ -471,6 +502,18 @@ class Run:
         self._side_keep = []
         self._side_windows = []
         self._side_used = False
+        # one event behind this node's weight gradients: the bucket hook waits for the events of the
+        # parameters in ITS bucket instead of for everything queued on the stream by then
+        ev = torch.cuda.Event()
+        ev.record(_SIDE[self.device])
+        for k in self.param_grads:
+            _SIDE_EVENTS[k] = ev
+        # ... and whoever runs last joins: the last node (stage 1) does it itself (join_side); if that one
+        # deferred too, or never runs, the end-of-pass callback does
+        if not _CALLBACK_QUEUED.get(self.device):
+            _CALLBACK_QUEUED[self.device] = True
+            dev = self.device
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(dev))
 
     # -- weight packing ------------------------------------------------------------
     def _packed_buffer(self, owner, tag, n, zero):

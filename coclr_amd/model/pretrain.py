@@ -29,11 +29,17 @@ from .. import optim as _optim
 from ..backbone.select_backbone import select_backbone
 
 _CHUNK = 32768   # elements per workgroup of the momentum kernel
-# shuffle-BN exchange at world > 1: "routed" (RCCL all_to_all_single, default), "allgather" (the
-# reference's own scheme), "pull" (each rank reads its clips out of its peers' hipIpc-mapped staging
-# buffers with one HIP kernel; validated with two ranks on one GPU, opt-in until run over xGMI)
-_SHUFFLE_MODE = os.environ.get("COCLR_SHUFFLE", "routed")
-_ROUTED_SHUFFLE = _SHUFFLE_MODE != "allgather"
+# shuffle-BN exchange at world > 1:
+#   "pull"      each rank reads its clips out of its peers' hipIpc-mapped staging buffers with one HIP
+#               kernel (coclr_pull_rows): the hand-written exchange, no collective on the data path
+#   "routed"    RCCL all_to_all_single of exactly the clips each rank will encode
+#   "allgather" the reference's own scheme (all-gather, keep B of B*world)
+#   "auto"      (default) the first forward on device tensors maps the peers, runs the routed exchange AND the
+#               pull on the same permutation, compares what arrived bit for bit on every rank, and stays on
+#               "pull" if all agree -- "routed" otherwise (mapping refused, any difference): the kernel earns
+#               its place on the data path at run time instead of behind an environment variable
+_SHUFFLE_MODE = os.environ.get("COCLR_SHUFFLE", "auto")
+_SHUFFLE_INFO = {"requested": _SHUFFLE_MODE}       # how the mode in force was arrived at (bench.py prints it)
 _OVERLAP_KEYS = os.environ.get("COCLR_OVERLAP_KEYS", "1") != "0"
 _GRAPHS = os.environ.get("COCLR_GRAPHS", "1") != "0"
 
@@ -625,8 +631,16 @@ class InfoNCE(nn.Module):
             InfoNCE._HOST_GROUP = g
         return g
 
+    def _host_perm(self, BW):
+        """The step's permutation of the global batch, identical on every rank, on the HOST: CPU randperm
+        (same RNG use as the reference, :112) broadcast from rank 0 over the gloo side channel (ref :115)."""
+        perm = torch.randperm(BW)
+        _coll("host broadcast of the permutation over gloo (pretrain._host_perm; ref :115)",
+              lambda: dist.broadcast(perm, src=0, group=self._host_group()), 8 * BW)
+        return perm
+
     @torch.no_grad()
-    def _routed_shuffle(self, x2):
+    def _routed_shuffle(self, x2, perm=None):
         """Shuffle-BN input exchange (ref :98-124) as a routed all-to-all.
 
         The reference all-gathers every rank's key clips (201 MB out, 1.4 GB in per rank at
@@ -640,9 +654,8 @@ class InfoNCE(nn.Module):
         world, rank = _world()
         B = x2.shape[0]
         BW = B * world
-        perm = torch.randperm(BW)                         # same RNG use as the reference (:112)
-        _coll("host broadcast of the permutation over gloo (pretrain._routed_shuffle; ref :115)",
-              lambda: dist.broadcast(perm, src=0, group=self._host_group()), 8 * BW)
+        if perm is None:
+            perm = self._host_perm(BW)
         pn = perm.numpy()
         src = pn // B
         mine = np.nonzero(src == rank)[0]
@@ -725,10 +738,11 @@ class InfoNCE(nn.Module):
         if int(ok) == 0:
             global _SHUFFLE_MODE
             import warnings
-            warnings.warn("coclr_amd: COCLR_SHUFFLE=pull is not available here (%s on rank %d); every "
-                          "rank falls back to the routed all-to-all"
-                          % (err if err is not None else "a peer could not map the staging buffers", rank))
+            why = "%s on rank %d" % (err if err is not None else "a peer could not map the staging buffers", rank)
+            warnings.warn("coclr_amd: the peer row pull is not available here (%s); every rank uses the "
+                          "routed all-to-all" % why)
             _SHUFFLE_MODE = "routed"
+            _SHUFFLE_INFO.update(selected="routed", why="peer mapping refused: " + why[:200])
             self.__dict__["_peer_stage_state"] = None
             return None
         B = x2.shape[0]
@@ -742,7 +756,7 @@ class InfoNCE(nn.Module):
         return st
 
     @torch.no_grad()
-    def _pull_shuffle(self, x2):
+    def _pull_shuffle(self, x2, perm=None):
         """Shuffle-BN input exchange (ref :98-124) as a row pull: every rank parks its B key clips
         in a buffer its peers have mapped, and one HIP kernel (`coclr_pull_rows`) fetches the B clips
         this rank has to encode straight from their owners -- B clips cross the fabric per rank, no
@@ -758,9 +772,8 @@ class InfoNCE(nn.Module):
             return None
         par = st["step"] & 1
         st["step"] += 1
-        perm = torch.randperm(BW)                         # same RNG use as the reference (:112)
-        _coll("host broadcast of the permutation over gloo (pretrain._pull_shuffle; ref :115)",
-              lambda: dist.broadcast(perm, src=0, group=self._host_group()), 8 * BW)
+        if perm is None:
+            perm = self._host_perm(BW)
         pn = perm.numpy()
         dev = x2.device
         if st["host"] is None:
@@ -784,15 +797,59 @@ class InfoNCE(nn.Module):
         return recv, st["ident"], st["dev"][B:]
 
     @torch.no_grad()
+    def _auto_shuffle(self, x2):
+        """COCLR_SHUFFLE=auto, first exchange: routed AND pull on one permutation, compared bit for bit.
+        Returns the routed result (the step proceeds on it) and leaves _SHUFFLE_MODE decided: "pull" when
+        every rank received exactly the same clips both ways, "routed" otherwise.  One host synchronisation,
+        once per process."""
+        global _SHUFFLE_MODE
+        world, rank = _world()
+        if not x2.is_cuda:
+            _SHUFFLE_MODE = "routed"
+            _SHUFFLE_INFO.update(selected="routed", why="host tensors: nothing to map")
+            return self._routed_shuffle(x2)
+        if self._peer_stage(x2) is None:              # collective; on refusal every rank is on "routed" now
+            return self._routed_shuffle(x2)
+        perm = self._host_perm(x2.shape[0] * world)
+        routed = self._routed_shuffle(x2, perm=perm)
+        same, why = 0, "the pull raised"
+        try:
+            pulled = self._pull_shuffle(x2, perm=perm)
+            if pulled is not None:
+                same = int(torch.equal(routed[0].index_select(0, routed[1]), pulled[0])
+                           and torch.equal(routed[2], pulled[2]))
+                why = "the clips pulled differ from the clips routed" if not same else ""
+        except Exception as e:            # the verdict below must still be reached by every rank
+            why = "the pull raised %s" % (str(e)[:160],)
+        ok = torch.tensor([same], dtype=torch.int32)
+        _coll("host all_reduce(MIN) 'pull == routed on every rank' over gloo (pretrain._auto_shuffle)",
+              lambda: dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self._host_group()))
+        if int(ok) == 1:
+            _SHUFFLE_MODE = "pull"
+            _SHUFFLE_INFO.update(selected="pull", why="first exchange: pulled clips bit-identical to the routed "
+                                                      "all-to-all's on every rank")
+        else:
+            import warnings
+            _SHUFFLE_MODE = "routed"
+            _SHUFFLE_INFO.update(selected="routed", why=why or "a peer's pull differed or raised")
+            warnings.warn("coclr_amd: peer row pull rejected (%s); every rank stays on the routed all-to-all"
+                          % _SHUFFLE_INFO["why"])
+        return routed
+
+    @torch.no_grad()
     def _encode_keys(self, x2, pre=None):
         """Key path: [pre = momentum update] -> shuffle -> encoder_k -> normalise -> un-shuffle.
         Returns (k for this rank's samples, keys of the whole global batch in order)."""
         world, rank = _world()
         B = x2.shape[0]
-        pulled = self._pull_shuffle(x2) if world > 1 and _SHUFFLE_MODE == "pull" else None
+        pulled = None
+        if world > 1 and _SHUFFLE_MODE == "auto":
+            pulled = self._auto_shuffle(x2)
+        elif world > 1 and _SHUFFLE_MODE == "pull":
+            pulled = self._pull_shuffle(x2)
         if pulled is not None:
             src, n_index, idx_unshuffle = pulled
-        elif world > 1 and _ROUTED_SHUFFLE:
+        elif world > 1 and _SHUFFLE_MODE != "allgather":
             src, n_index, idx_unshuffle = self._routed_shuffle(x2)
         elif world > 1:
             # the reference's own scheme (all-gather, keep B of B*world): COCLR_SHUFFLE=allgather

@@ -71,8 +71,16 @@ def collective(name, fn, nbytes=0, device=None):
                 torch.cuda.synchronize(device)
             timing.append((name, int(nbytes), (time.perf_counter() - t0) * 1e3))
     except Exception as e:
-        raise RuntimeError("coclr_amd: collective '%s' failed after %.1f s: %s"
-                           % (name, time.perf_counter() - t0, e)) from e
+        msg = "coclr_amd: collective '%s' failed after %.1f s: %s" % (name, time.perf_counter() - t0, e)
+        # keep the backend's exception TYPE (DistBackendError / DistNetworkError are what elastic launchers
+        # catch to restart); anything that cannot be rebuilt from a message becomes a RuntimeError
+        err = None
+        if isinstance(e, RuntimeError):
+            try:
+                err = type(e)(msg)
+            except Exception:
+                err = None
+        raise (err if err is not None else RuntimeError(msg)) from e
     return out
 
 
@@ -81,19 +89,35 @@ class _HookState:
     def __init__(self, group):
         self.group = group
         self.seen = {}        # bucket index -> (buffer address, #parameters) already published
-        self.published = {}   # id(param) -> weakref(param): slots this wrapper handed to the engine
+        self.published = {}   # id(param) -> (weakref(param), address of the view handed to the engine)
         self.verified = set() # bucket indices whose published views DDP has been seen to accept
 
 
 def _drop_slots(published):
     """The wrapper is gone (re-wrap, or training continues on the bare model): its bucket storage must not
-    stay alive -- or keep being handed out as `.grad` memory -- through the engine's slot table."""
+    stay alive -- or keep being handed out as `.grad` memory -- through the engine's slot table.  Only slots
+    that still hold THIS wrapper's view are dropped: the cyclic gc may finalise a dead wrapper long after
+    a new wrapper around the same model has published its own views for the same parameters."""
     from . import engine
-    for ref in published.values():
+    for ref, addr in published.values():
         p = ref()
-        if p is not None:
+        if p is None:
+            continue
+        slot = engine._GRAD_SLOTS.get(id(p))
+        if slot is not None and slot[0]() is p and slot[1].data_ptr() == addr:
             engine.set_grad_slot(p, None)
     published.clear()
+
+
+def _still_published(state, params, grads):
+    """Does the engine still hold the views this wrapper published for the bucket?  (Checked on the first and
+    the last parameter: slots are dropped or replaced a whole wrapper at a time.)"""
+    from . import engine
+    for i in (0, len(params) - 1):
+        slot = engine._GRAD_SLOTS.get(id(params[i]))
+        if slot is None or slot[0]() is not params[i] or slot[1].data_ptr() != grads[i].data_ptr():
+            return False
+    return True
 
 
 def _register_lazily(ddp, _inputs):
@@ -123,24 +147,27 @@ def bucket_hook(state, bucket):
     buf = bucket.buffer()
     sig = (buf.data_ptr(), buf.numel())
     idx = bucket.index()
-    if state.seen.get(idx) != sig:
+    params, grads = bucket.parameters(), bucket.gradients()
+    if state.seen.get(idx) != sig or not _still_published(state, params, grads):
+        # new bucket memory -- or somebody (another wrapper around the same model, a late finaliser of a dead
+        # one) has taken the engine's slots since: publish again, verification starts over
         import weakref
-        for p, g in zip(bucket.parameters(), bucket.gradients()):
+        for p, g in zip(params, grads):
             engine.set_grad_slot(p, g)
-            state.published[id(p)] = weakref.ref(p)
+            state.published[id(p)] = (weakref.ref(p), g.data_ptr())
         state.seen[idx] = sig
         state.verified.discard(idx)
     elif idx not in state.verified:
         # same bucket memory as last time: if every gradient DDP holds for it IS the view the engine was
         # given, DDP copied nothing this pass and will not next time either (engine._SLOTS_VERIFIED)
-        params = bucket.parameters()
-        if all(p.grad is not None and p.grad.data_ptr() == g.data_ptr()
-               for p, g in zip(params, bucket.gradients())):
+        if all(p.grad is not None and p.grad.data_ptr() == g.data_ptr() for p, g in zip(params, grads)):
             engine._SLOTS_VERIFIED.update(id(p) for p in params)
             state.verified.add(idx)
     group = state.group if state.group is not None else dist.group.WORLD
     world = dist.get_world_size(group)
     if world == 1:
+        # nothing to reduce; a node that deferred its join is ordered in front of the optimiser by the
+        # engine's end-of-backward callback (engine.Run.defer_side)
         fut = torch.futures.Future()
         fut.set_result(buf)
         return fut
@@ -159,7 +186,15 @@ def bucket_hook(state, bucket):
         if prep is None:
             prep = _PREP[buf.device] = torch.cuda.Stream(device=buf.device)
         prep.wait_stream(torch.cuda.current_stream(buf.device))
-        prep.wait_stream(side)
+        # ... behind the weight gradients of THIS bucket only: every node records one event on the weight-
+        # gradient stream when its last weight gradient has been enqueued (engine.side_events_for); waiting
+        # for the whole stream would also wait for later stages' weight gradients that are already queued
+        events = engine.side_events_for(params)
+        if events is None:
+            prep.wait_stream(side)
+        else:
+            for ev in events:
+                prep.wait_event(ev)
         with torch.cuda.stream(prep):
             buf.div_(world)
             work = collective("ddp bucket %d all_reduce (parallel.bucket_hook; main_nce.py:172)" % idx,

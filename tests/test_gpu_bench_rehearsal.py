@@ -1,6 +1,7 @@
 """bench.py at N = 2 exactly as the driver launches it (torch.distributed.run, one process per rank) with
-both ranks on ONE MI355X over gloo (tests/bench_rehearse_gpu.py): the first-contact evidence block must come
-out complete and the replicas must be BIT-identical after a full step with the real kernels."""
+both ranks on ONE MI355X over gloo (tests/bench_rehearse_gpu.py): supervisors, children, the self-check of
+one steady-state step against the serial configuration with the REAL kernels, streams, graph replay, the
+single-launch Adam and the bucket hook -- and the exchange scheme chosen at run time."""
 import json
 import os
 import subprocess
@@ -10,15 +11,32 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+CASES = {
+    # name: (environment, expected shuffle mode, expected rung)
+    "auto": ({}, "pull", 0),
+    "allgather": ({"COCLR_SHUFFLE": "allgather"}, "allgather", 0),
+    "pull_refused": ({"COCLR_BENCH_FAULT": "pull_map"}, "routed", 0),
+    "defer_race": ({"COCLR_BENCH_FAULT": "defer"}, "pull", 1),
+}
 
-@pytest.mark.parametrize("shuffle", ["routed", "allgather"])
-def test_bench_n2_rehearsal_on_one_gpu(shuffle):
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_bench_n2_rehearsal_on_one_gpu(case):
+    """auto          the default: peers mapped through hipIpc, routed all-to-all AND row pull on the first
+                     exchange, bit-identical on both ranks -> the HIP pull kernel is the data path from then on;
+                     joins deferred in the checked step; fast step == serial step bit for bit
+       allgather     the reference's own exchange, forced
+       pull_refused  rank 1 cannot export its staging buffers: both ranks agree and stay on the routed exchange
+       defer_race    a gradient lost while joins are deferred (only reachable with the real streams): replicas
+                     still agree, the self-check does not -- the bench ends on rung 1 with a valid line"""
+    env_extra, shuffle, rung = CASES[case]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29761 + list(CASES).index(case)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29761" if shuffle == "routed" else "29762",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "bench_rehearse_gpu.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--batch", "8", "--moco-k", "2048"]
-    env = dict(os.environ, COCLR_SHUFFLE=shuffle, COCLR_QUIET="1")
+    env = dict(os.environ, COCLR_QUIET="1", **env_extra)
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -26,13 +44,29 @@ def test_bench_n2_rehearsal_on_one_gpu(shuffle):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and "REHEARSAL" in rec["data"]
     assert rec["value"] > 0 and rec["config"]["final_loss"] == rec["config"]["final_loss"]
-    mg = rec["multi_gpu"]
-    assert mg["shuffle_mode"] == shuffle and mg["split_stages"] is True
+    mg, sc = rec["multi_gpu"], rec["self_check"]
+    assert mg["shuffle_mode"] == shuffle and mg["split_stages"] is True, mg["shuffle_selection"]
     assert mg["cross_rank"]["replicas_identical"] is True, mg["cross_rank"]
     assert mg["cross_rank"]["logits_finite_on_every_rank"] is True
+    assert len(mg["attempts"]) == 1 and mg["attempts"][0]["ok"] is True
+    assert sc["passed"] is True and mg["rung"] == rung == sc["rung"], (sc["trials"], mg["rung"])
+    assert [t["bit_identical_to_serial_on_every_rank"] for t in sc["trials"]] == [False] * rung + [True]
+    # the checked step is a steady-state one: stages 2-5 left the weight-gradient stream un-joined
+    assert sc["deferred_nodes_in_checked_step"] >= 4, sc
+    if rung == 0:
+        assert rec["deferred_joins_per_step"] >= 4
     names = " | ".join(c["collective"] for c in mg["collectives"])
-    for what in (("all_to_all_single",) if shuffle == "routed" else ()) + (
-            "all_gather_into_tensor", "ddp bucket 0 all_reduce", "broadcast of the flat float32 buffer"):
+    want = {"pull": ("everybody has parked",), "routed": ("all_to_all_single",),
+            "allgather": ()}[shuffle] + ("all_gather_into_tensor", "ddp bucket 0 all_reduce",
+                                         "broadcast of the flat float32 buffer")
+    for what in want:
         assert what in names, (what, names)
-    print("N=2 rehearsal (%s): %.1f clips/s, collectives %.2f ms/step serialised"
-          % (shuffle, rec["value"], mg["collectives_ms_per_step_serialised"]))
+    sel = mg["shuffle_selection"]
+    if case == "auto":
+        assert sel["requested"] == "auto" and sel["selected"] == "pull" and "bit-identical" in sel["why"]
+    if case == "pull_refused":
+        assert sel["selected"] == "routed" and "refused" in sel["why"]
+    print("N=2 rehearsal (%s): %.1f clips/s, shuffle %s (%.3f ms/step serialised), rung %d, collectives %.2f "
+          "ms/step serialised" % (case, rec["value"], mg["shuffle_mode"],
+                                  mg["shuffle_exchange_ms_per_step_serialised"], mg["rung"],
+                                  mg["collectives_ms_per_step_serialised"]))

@@ -61,7 +61,6 @@ def _worker(rank, world, kind, port, q):
 
         def run(mode):
             impl._SHUFFLE_MODE = mode
-            impl._ROUTED_SHUFFLE = mode != "allgather"
             model = build_model(cfg, product).cuda()
             ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
             opt = torch.optim.Adam([{"params": p} for _, p in ddp.named_parameters()], lr=1e-3,
@@ -107,6 +106,11 @@ def _worker(rank, world, kind, port, q):
         gold["steps"] = gold["steps"][:1]
         outs_rt, _ = run("routed")
         assert torch.equal(outs_rt[0], outs_ag[0]), "routed all-to-all and all-gather exchange disagree"
+        # ... and the default, COCLR_SHUFFLE=auto: the first exchange runs routed AND pull, finds them
+        # bit-identical on both ranks and leaves the process on the HIP row pull
+        outs_auto, _ = run("auto")
+        assert impl._SHUFFLE_MODE == "pull" and impl._SHUFFLE_INFO["selected"] == "pull", impl._SHUFFLE_INFO
+        assert torch.equal(outs_auto[0], outs_ag[0]), "auto-selected exchange and all-gather exchange disagree"
         # the two exchange schemes deliver the same clips: the first step is bit-identical; later steps
         # are held to 5e-3 (the two runs see different allocator / graph-capture histories; nothing in
         # the kernels is order-dependent any more, but Adam at initialisation would turn a single

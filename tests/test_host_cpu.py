@@ -375,7 +375,7 @@ def _multi_rank_worker(rank, world, kind, port, q):
         assert K % (B * world) == 0
 
         def run(routed):
-            impl._ROUTED_SHUFFLE = routed
+            impl._SHUFFLE_MODE = "routed" if routed else "allgather"
             torch.manual_seed(0)
             if kind == "infonce":
                 model = product.InfoNCE('s3d', 128, K, 0.999, 0.07)
@@ -452,25 +452,33 @@ def test_four_and_eight_rank_gloo(world, kind, port):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_bench_launch_contract_dry_run(world):
-    """bench.py launched exactly as the driver launches it (torch.distributed.run, one process per
-    rank), on the host with the ATen double: one JSON line from rank 0 with the contract's fields,
-    whole-job value = B*world*steps/time, K = 16384 and weak scaling at world > 1."""
+def _bench_dry_run(world, port, extra_env=None, extra_args=()):
+    """bench.py exactly as the driver launches it (torch.distributed.run, one process per rank) on the host
+    with the ATen double; returns (the ONE JSON line rank 0 printed, stderr)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(29720 + world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "bench_dryrun.py"), "--gpus", str(world), "--steps", "2",
-           "--warmup", "1"]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+           "--warmup", "1"] + list(extra_args)
+    env = dict(os.environ, OMP_NUM_THREADS="1", COCLR_QUIET="1", **(extra_env or {}))
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    rec = json.loads(lines[0])
+    return json.loads(lines[0]), out.stderr
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_bench_launch_contract_dry_run(world):
+    """One JSON line from rank 0 with the contract's fields, whole-job value = B*world*steps/time, K = 16384
+    and weak scaling at world > 1.  At world 8 a fault is injected into the bucket hook (a bucket all-reduced
+    with a wrong gradient in it -- identical on every rank, so replicas still agree): the self-check must
+    see it and the bench must end, with a valid value, on the rung that switches the hook off."""
+    fault = {"COCLR_BENCH_FAULT": "hook"} if world == 8 else None
+    rec, _ = _bench_dry_run(world, 29720 + world, fault)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in rec, key
@@ -479,13 +487,18 @@ def test_bench_launch_contract_dry_run(world):
     assert rec["config"]["global_batch"] == 2 * world and "DRY RUN" in rec["data"]
     assert ("moco-k=16384" in rec["config"]["workload"]) == (world > 1)
     assert abs(rec["value"] - 2 * world * 2 / (rec["ms_per_step"] * 2e-3)) <= 0.02 * rec["value"]
+    # the fast-vs-serial bit-identity check of one step runs at every world size
+    sc = rec["self_check"]
+    assert sc["passed"] is True and sc["tensors_compared"] > 1000
+    assert sc["trials"][0]["rung"] == 0
     if world == 1:
-        assert "multi_gpu" not in rec
+        assert "multi_gpu" not in rec and sc["rung"] == 0
         return
     # first-contact evidence: one checked step with cross-rank digests, then the
     # per-collective wall times of two instrumented steps
     mg = rec["multi_gpu"]
     assert mg["shuffle_mode"] == "routed" and mg["split_stages"] is True
+    assert mg["shuffle_selection"]["requested"] == "auto"        # host tensors: nothing to pull
     assert mg["cross_rank"]["replicas_identical"] is True, mg["cross_rank"]
     assert mg["cross_rank"]["logits_finite_on_every_rank"] is True
     assert {"queue", "queue_ptr", "encoder_q.parameters", "encoder_k.parameters"} <= set(mg["cross_rank"]["fields"])
@@ -494,6 +507,45 @@ def test_bench_launch_contract_dry_run(world):
                  "broadcast of the flat float32 buffer", "host broadcast of the permutation"):
         assert what in names, (what, names)
     assert all(c["calls_per_step"] == 1.0 and c["ms_per_call"] > 0 for c in mg["collectives"])
+    assert mg["attempts"] == [{"attempt": 0, "started_on_rung": 0, "rung_name": "fast", "ok": True,
+                               "exit_codes": [0] * world}]
+    if world == 8:
+        # the injected race: rungs 0 and 1 differ from the serial step, rung 2 (no hook) matches, and THAT is timed
+        assert mg["rung"] == 2 and mg["rung_name"] == "-hook" and sc["rung"] == 2
+        assert [t["bit_identical_to_serial_on_every_rank"] for t in sc["trials"]] == [False, False, True]
+        assert mg["cross_rank"]["replicas_identical"] is True      # ... which replicas-identical cannot see
+    else:
+        assert mg["rung"] == 0 and len(sc["trials"]) == 1
+
+
+@pytest.mark.parametrize("fault,rung,attempts", [("defer", 1, 1), ("graphs", 5, 1), ("routed_raises", 4, 2),
+                                                 ("routed_hangs", 4, 2)])
+def test_bench_degradation_ladder(fault, rung, attempts):
+    """a fault at each kind of rung, and bench.py still finishes with ONE valid line
+    whose `multi_gpu.rung` names what had to be switched off.
+      defer / graphs   a wrong result tied to the switch (a lost gradient while joins are deferred; keys
+                       off by 1e-3 while the key encoder is replayed): found by the self-check, walked down
+                       IN PROCESS to the first rung that is bit-identical to the serial step
+      routed_raises    the backend refuses all_to_all_single on every rank: the attempt ends, the supervisors
+                       read WHICH exchange failed and start a new set of processes on the all-gather rung
+      routed_hangs     one rank never enters the exchange: the watchdog names it after --hang-timeout and
+                       ends the attempt; same recovery"""
+    rec, err = _bench_dry_run(2, 29750 + rung + attempts, {"COCLR_BENCH_FAULT": fault},
+                              ("--hang-timeout", "6"))
+    mg = rec["multi_gpu"]
+    assert rec["value"] > 0 and rec["n_gpus"] == 2
+    assert mg["rung"] == rung, (mg["rung"], mg["attempts"], rec["self_check"]["trials"])
+    assert rec["self_check"]["passed"] is True
+    assert len(mg["attempts"]) == attempts and mg["attempts"][-1]["ok"] is True
+    if attempts == 2:
+        first = mg["attempts"][0]
+        assert first["ok"] is False and first["started_on_rung"] == 0
+        assert "all_to_all_single" in first["failed_ranks"][0]["last_collective"]
+        assert mg["attempts"][1]["started_on_rung"] == 4 and mg["switches"]["shuffle"] == "allgather"
+        assert "bench supervisor: attempt 0 on rung 0 (fast) failed" in err
+    else:
+        assert [t["bit_identical_to_serial_on_every_rank"] for t in rec["self_check"]["trials"]] == \
+            [False] * rung + [True]
 
 
 def test_bench_watchdog_names_the_stuck_collective():
@@ -555,7 +607,7 @@ def _pull_fallback_worker(rank, world, port, q):
             warnings.simplefilter("always")
             got = run("pull")
         assert impl._SHUFFLE_MODE == "routed", "the fallback must switch every rank to the routed exchange"
-        assert any("falls back to the routed" in str(w.message) for w in caught)
+        assert any("every rank uses the routed" in str(w.message) for w in caught)
         ref = run("routed")
         assert torch.equal(got, ref)
         dist.destroy_process_group()
