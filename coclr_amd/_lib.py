@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -54,6 +54,12 @@ class BnBwdCall(C.Structure):
         ("relu", i32), ("training", i32), ("part", vp * 2), ("part_ntiles", i32 * 2)]
 
 
+class GemmEpilogue(C.Structure):
+    """Mirror of `coclr_gemm_epilogue`."""
+    _fields_ = [("mode", i32), ("S", i32), ("a", vp), ("lda", i64), ("b", vp), ("y", vp), ("inv_norm", vp),
+                ("out2", vp), ("f", f32), ("rowsum", vp)]
+
+
 _P = C.POINTER
 _SIGNATURES = {
     "coclr_abi_version": [],
@@ -89,6 +95,8 @@ _SIGNATURES = {
     "coclr_gemm_workspace": [i32, i32, i32, i32, _P(i64)],
     "coclr_gemm": [vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, i32, i32, f32, i32, i32, i32, vp,
                    vp],
+    "coclr_gemm_fused": [vp, i64, i64, vp, i64, i64, vp, i64, vp, i32, i32, i32, f32, i32, i32, vp,
+                         _P(GemmEpilogue), vp],
     "coclr_l2norm_fwd": [vp, vp, vp, i32, i32, f32, vp],
     "coclr_l2norm_bwd": [vp, vp, vp, vp, i32, i32, vp],
     "coclr_nce_logits_fwd": [vp, vp, vp, vp, i32, i32, i32, f32, vp],

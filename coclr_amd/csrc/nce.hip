@@ -14,6 +14,26 @@
 
 namespace {
 
+// The epilogue arithmetic of the head, with every rounding pinned: the same value must come out whether an
+// operation runs as its own launch (l2norm_fwd_kernel after the fold) or inside the fold kernel of
+// coclr_gemm_fused -- the compiler is otherwise free to contract `a * b + c` into one fused multiply-add in
+// one kernel and not in the other (it did: F.normalize differed in the last bit between the two forms).
+__device__ __forceinline__ float ep_scale_bias(float s, float alpha, const float* bias, int n) {
+  float v = __fmul_rn(s, alpha);
+  if (bias) v = __fadd_rn(v, bias[n]);
+  return v;
+}
+__device__ __forceinline__ float ep_fma(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+__device__ __forceinline__ float ep_inv_norm(float ss, float eps) { return __fdiv_rn(1.f, fmaxf(__fsqrt_rn(ss), eps)); }
+// (dy - y * dot) * inv
+__device__ __forceinline__ float ep_norm_bwd(float dy, float y, float dot, float inv) {
+  return __fmul_rn(__fmaf_rn(-y, dot, dy), inv);
+}
+// dq + (dl0 * inv_T) * k
+__device__ __forceinline__ float ep_lpos(float dq, float dl0, float inv_T, float k) {
+  return __fmaf_rn(__fmul_rn(dl0, inv_T), k, dq);
+}
+
 // ---------------------------------------------------------------------------
 // C[m][n] (+)= act(alpha * sum_k A(m,k) B(k,n) + bias[n])
 // A(m,k) at a[m*sam + k*sak], B(k,n) at b[k*sbk + n*sbn].
@@ -27,7 +47,14 @@ struct GemmArgs {
   int M, N, K, kslice;
   float alpha;
   int relu, accumulate, splits;
-  float* part;   // [splits][M][N] when splits > 1
+  float* part;   // [splits][M][N] when the product goes through the fold kernel
+  // ---- coclr_gemm_fused: the row-level operation that follows the product, applied by the kernel that folds
+  // the split-K partials (one pass over the partials instead of fold + one or two more launches)
+  int to_part, ep_mode, ep_S;
+  const float* ep_a; long ep_lda;
+  const float* ep_b; const float* ep_y; const float* ep_inv;
+  float* ep_out2; float ep_f;
+  float* rowsum;   // splits == 1: rowsum[m] = sum_k A(m,k), written by the workgroups of the first tile column
 };
 
 template <bool TA, bool TB>
@@ -47,6 +74,7 @@ gemm32x128_kernel(const GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float rs = 0.f;
 
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();
@@ -67,6 +95,10 @@ gemm32x128_kernel(const GemmArgs g) {
       Bs[k * LDB + n] = (gn < g.N && gk < kend) ? g.b[gk * g.sbk + gn * g.sbn] : 0.f;
     }
     __syncthreads();
+    if (g.rowsum && blockIdx.x == 0 && tid < 32) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) rs += As[k * LDA + tid];
+    }
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
       const int k = 2 * s + half;
@@ -75,20 +107,20 @@ gemm32x128_kernel(const GemmArgs g) {
     }
   }
 
+  if (g.rowsum && blockIdx.x == 0 && tid < 32 && m0 + tid < g.M) g.rowsum[m0 + tid] = rs;
   const int gn = n0 + wave * 32 + l31;
   if (gn >= g.N) return;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int gm = m0 + (i & 3) + 8 * (i >> 2) + 4 * half;
     if (gm >= g.M) continue;
-    if (g.splits > 1) {
+    if (g.to_part) {
       g.part[((long)split * g.M + gm) * g.N + gn] = acc[i];
     } else {
-      float v = acc[i] * g.alpha;
-      if (g.bias) v += g.bias[gn];
+      float v = ep_scale_bias(acc[i], g.alpha, g.bias, gn);
       if (g.relu) v = fmaxf(v, 0.f);
       float* d = g.c + gm * g.ldc + gn;
-      *d = g.accumulate ? *d + v : v;
+      *d = g.accumulate ? __fadd_rn(*d, v) : v;
     }
   }
 }
@@ -101,11 +133,79 @@ __global__ void gemm_splitk_reduce_kernel(const GemmArgs g) {
     for (int k = 0; k < g.splits; ++k) s += g.part[(long)k * MN + e];
     const long m = e / g.N;
     const int n = (int)(e - m * g.N);
-    float v = s * g.alpha;
-    if (g.bias) v += g.bias[n];
+    float v = ep_scale_bias(s, g.alpha, g.bias, n);
     if (g.relu) v = fmaxf(v, 0.f);
+    if (g.ep_mode == 1) v = g.ep_a[m * g.ep_lda + n] > 0.f ? v : 0.f;          // ReLU backward
     float* d = g.c + m * g.ldc + n;
-    *d = g.accumulate ? *d + v : v;
+    *d = g.accumulate ? __fadd_rn(*d, v) : v;
+  }
+}
+
+// fold + global-average-pool backward: output element (m, n, s) = fold(m, n) / S.  The S threads of a
+// plane read the same partials (one transaction per wave and split) and write S consecutive floats.
+__global__ void gemm_splitk_reduce_expand_kernel(const GemmArgs g) {
+  const long MN = (long)g.M * g.N;
+  const long total = MN * g.ep_S;
+  const float inv = 1.f / (float)g.ep_S;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const long mn = e / g.ep_S;
+    float s = 0.f;
+    for (int k = 0; k < g.splits; ++k) s += g.part[(long)k * MN + mn];
+    const float v = ep_scale_bias(s, g.alpha, g.bias, (int)(mn % g.N));
+    g.c[e] = __fmul_rn(v, inv);
+  }
+}
+
+// fold + a ROW operation, one wave per output row (lane l owns columns l, l + 64, ...; N <= 64 * RC):
+//   mode 2  F.normalize: c = v / max(||v||, f), out2 = 1 / max(||v||, f)        (as l2norm_fwd_kernel)
+//   mode 3  v += a[m*lda] * f * b[m][n] (l_pos term), then c = (v - y <y, v>) * inv_norm[m]
+//                                                                                   (as l2norm_bwd_kernel)
+template <int RC>
+__global__ void __launch_bounds__(256)
+gemm_splitk_reduce_rows_kernel(const GemmArgs g) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= g.M) return;
+  const long MN = (long)g.M * g.N;
+  float v[RC];
+#pragma unroll
+  for (int j = 0; j < RC; ++j) {
+    const int n = lane + 64 * j;
+    float s = 0.f;
+    if (n < g.N)
+      for (int k = 0; k < g.splits; ++k) s += g.part[(long)k * MN + (long)row * g.N + n];
+    float x = 0.f;
+    if (n < g.N) {
+      x = ep_scale_bias(s, g.alpha, g.bias, n);
+      if (g.relu) x = fmaxf(x, 0.f);
+      if (g.ep_mode == 3) x = ep_lpos(x, g.ep_a[row * g.ep_lda], g.ep_f, g.ep_b[(long)row * g.N + n]);
+    }
+    v[j] = x;
+  }
+  if (g.ep_mode == 2) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < RC; ++j)
+      if (lane + 64 * j < g.N) ss = ep_fma(v[j], v[j], ss);
+    ss = wave_sum(ss);
+    const float inv = ep_inv_norm(ss, g.ep_f);
+#pragma unroll
+    for (int j = 0; j < RC; ++j)
+      if (lane + 64 * j < g.N) g.c[row * g.ldc + lane + 64 * j] = __fmul_rn(v[j], inv);
+    if (lane == 0 && g.ep_out2) g.ep_out2[row] = inv;
+  } else {
+    float y[RC];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < RC; ++j) {
+      y[j] = lane + 64 * j < g.N ? g.ep_y[(long)row * g.N + lane + 64 * j] : 0.f;
+      if (lane + 64 * j < g.N) dot = ep_fma(v[j], y[j], dot);
+    }
+    dot = wave_sum(dot);
+    const float inv = g.ep_inv[row];
+#pragma unroll
+    for (int j = 0; j < RC; ++j)
+      if (lane + 64 * j < g.N) g.c[row * g.ldc + lane + 64 * j] = ep_norm_bwd(v[j], y[j], dot, inv);
   }
 }
 
@@ -119,10 +219,10 @@ l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __r
   if (row >= rows) return;
   const float* xp = x + (long)row * D;
   float ss = 0.f;
-  for (int i = lane; i < D; i += 64) ss += xp[i] * xp[i];
+  for (int i = lane; i < D; i += 64) ss = ep_fma(xp[i], xp[i], ss);
   ss = wave_sum(ss);
-  const float inv = 1.f / fmaxf(sqrtf(ss), eps);
-  for (int i = lane; i < D; i += 64) y[(long)row * D + i] = xp[i] * inv;
+  const float inv = ep_inv_norm(ss, eps);
+  for (int i = lane; i < D; i += 64) y[(long)row * D + i] = __fmul_rn(xp[i], inv);
   if (lane == 0 && inv_norm) inv_norm[row] = inv;
 }
 
@@ -135,10 +235,10 @@ l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
   const float* dyp = dy + (long)row * D;
   const float* yp = y + (long)row * D;
   float dot = 0.f;
-  for (int i = lane; i < D; i += 64) dot += dyp[i] * yp[i];
+  for (int i = lane; i < D; i += 64) dot = ep_fma(dyp[i], yp[i], dot);
   dot = wave_sum(dot);
   const float inv = inv_norm[row];
-  for (int i = lane; i < D; i += 64) dx[(long)row * D + i] = (dyp[i] - yp[i] * dot) * inv;
+  for (int i = lane; i < D; i += 64) dx[(long)row * D + i] = ep_norm_bwd(dyp[i], yp[i], dot, inv);
 }
 
 // logits[b][0] = <q_b, k_b> * inv_T
@@ -260,7 +360,7 @@ __global__ void lpos_bwd_kernel(const float* __restrict__ dlogits, const float* 
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
     const long b = e / D;
-    dq[e] += dlogits[b * ldl] * inv_T * k[e];
+    dq[e] = ep_lpos(dq[e], dlogits[b * ldl], inv_T, k[e]);
   }
 }
 
@@ -573,6 +673,37 @@ extern "C" int coclr_gemm_workspace(int M, int N, int K, int splits, int64_t* el
   return 0;
 }
 
+namespace {
+int launch_gemm(GemmArgs& g, int splits, hipStream_t stream) {
+  int kslice = cdiv(g.K, splits);
+  kslice = cdiv(kslice, 32) * 32;
+  g.kslice = kslice;
+  splits = cdiv(g.K, kslice);
+  g.splits = splits;
+  if (splits > 1) g.to_part = 1;
+  dim3 grid(cdiv(g.N, 128), cdiv(g.M, 32), splits);
+  const bool TA = (g.sam == 1 && g.sak != 1), TB = (g.sbk == 1 && g.sbn != 1);
+  if (TA && TB) hipLaunchKernelGGL((gemm32x128_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  else if (TA) hipLaunchKernelGGL((gemm32x128_kernel<true, false>), grid, dim3(256), 0, stream, g);
+  else if (TB) hipLaunchKernelGGL((gemm32x128_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm32x128_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  COCLR_LAUNCH_CHECK();
+  if (!g.to_part) return 0;
+  if (g.ep_mode == 2 || g.ep_mode == 3) {
+    const dim3 rgrid(cdiv((long)g.M * 64, 256));
+    if (g.N <= 128) hipLaunchKernelGGL((gemm_splitk_reduce_rows_kernel<2>), rgrid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_splitk_reduce_rows_kernel<8>), rgrid, dim3(256), 0, stream, g);
+  } else if (g.ep_mode == 4) {
+    hipLaunchKernelGGL(gemm_splitk_reduce_expand_kernel, dim3(grid1d((long)g.M * g.N * g.ep_S, 8192)),
+                       dim3(256), 0, stream, g);
+  } else {
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(grid1d((long)g.M * g.N)), dim3(256), 0, stream, g);
+  }
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
 extern "C" int coclr_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk,
                           int64_t sbn, float* c, int64_t ldc, const float* bias, int M, int N,
                           int K, float alpha, int relu, int accumulate, int splits,
@@ -580,28 +711,41 @@ extern "C" int coclr_gemm(const float* a, int64_t sam, int64_t sak, const float*
   hipStream_t stream = (hipStream_t)stream_;
   if (M <= 0 || N <= 0 || K <= 0 || splits < 1) return COCLR_EINVAL;
   if (splits > 1 && !workspace) return COCLR_EINVAL;
-  GemmArgs g;
+  GemmArgs g = {};
   g.a = a; g.b = b; g.c = c; g.bias = bias;
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K;
-  int kslice = cdiv(K, splits);
-  kslice = cdiv(kslice, 32) * 32;
-  g.kslice = kslice;
-  splits = cdiv(K, kslice);
-  g.splits = splits;
   g.alpha = alpha; g.relu = relu; g.accumulate = accumulate; g.part = workspace;
-  dim3 grid(cdiv(N, 128), cdiv(M, 32), splits);
-  const bool TA = (sam == 1 && sak != 1), TB = (sbk == 1 && sbn != 1);
-  if (TA && TB) hipLaunchKernelGGL((gemm32x128_kernel<true, true>), grid, dim3(256), 0, stream, g);
-  else if (TA) hipLaunchKernelGGL((gemm32x128_kernel<true, false>), grid, dim3(256), 0, stream, g);
-  else if (TB) hipLaunchKernelGGL((gemm32x128_kernel<false, true>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm32x128_kernel<false, false>), grid, dim3(256), 0, stream, g);
-  COCLR_LAUNCH_CHECK();
-  if (splits > 1) {
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(grid1d((long)M * N)), dim3(256), 0, stream, g);
-    COCLR_LAUNCH_CHECK();
-  }
-  return 0;
+  return launch_gemm(g, splits, stream);
+}
+
+// The same product with the row-level operation that follows it in the projection head applied by the fold
+// kernel (model/pretrain.py:49-54,153-154,175-182 and their backward): two launches per product, one for the
+// plain product with row sums.
+extern "C" int coclr_gemm_fused(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk,
+                                int64_t sbn, float* c, int64_t ldc, const float* bias, int M, int N,
+                                int K, float alpha, int relu, int splits, float* workspace,
+                                const coclr_gemm_epilogue* ep, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || !ep) return COCLR_EINVAL;
+  if (ep->mode < 0 || ep->mode > 4) return COCLR_EINVAL;
+  const bool direct = ep->mode == 0 && splits == 1;            // plain product (+ row sums), one launch
+  if (!direct && !workspace) return COCLR_EINVAL;
+  if ((ep->mode == 2 || ep->mode == 3) && N > 512) return COCLR_EINVAL;      // a row lives in one wave
+  if (ep->mode == 1 && !ep->a) return COCLR_EINVAL;
+  if (ep->mode == 3 && (!ep->a || !ep->b || !ep->y || !ep->inv_norm)) return COCLR_EINVAL;
+  if (ep->mode == 4 && ep->S <= 0) return COCLR_EINVAL;
+  if (ep->rowsum && splits != 1) return COCLR_EINVAL;
+  GemmArgs g = {};
+  g.a = a; g.b = b; g.c = c; g.bias = bias;
+  g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K;
+  g.alpha = alpha; g.relu = relu; g.accumulate = 0; g.part = workspace;
+  g.to_part = direct ? 0 : 1;
+  g.ep_mode = ep->mode; g.ep_S = ep->S;
+  g.ep_a = ep->a; g.ep_lda = ep->lda; g.ep_b = ep->b; g.ep_y = ep->y; g.ep_inv = ep->inv_norm;
+  g.ep_out2 = ep->out2; g.ep_f = ep->f; g.rowsum = ep->rowsum;
+  return launch_gemm(g, splits, stream);
 }
 
 extern "C" int coclr_l2norm_fwd(const float* x, float* y, float* inv_norm, int rows, int D,

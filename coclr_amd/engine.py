@@ -137,6 +137,18 @@ def set_grad_slot(param, view):
             del _GRAD_SLOTS[k_]
 
 
+def grad_out_for(p):
+    """Run.grad_out for code outside an engine run (the projection head, coclr_amd/model/pretrain.py): a
+    fresh alias of p's DistributedDataParallel bucket view when there is one and `.grad` is unset -- the
+    kernel then writes the gradient where DDP wants it and DDP copies nothing -- else new memory."""
+    slot = _GRAD_SLOTS.get(id(p)) if _GRAD_SLOTS else None
+    if slot is not None and slot[0]() is p and p.grad is None:
+        v = slot[1]
+        if v.device == p.device and v.shape == p.shape and v.dtype == p.dtype:
+            return v.view_as(v)
+    return torch.empty_like(p)
+
+
 class _Lane:
     def __init__(self, run, idx):
         self.run, self.idx, self.ctx = run, idx, None

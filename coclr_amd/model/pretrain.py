@@ -249,6 +249,138 @@ class _NceLogitsFn(torch.autograd.Function):
         return dq, None, None, None
 
 
+# ---------------------------------------------------------------------------------
+# The head as the training step runs it
+# ---------------------------------------------------------------------------------
+# Module by module (above) the projection head and the logits are 8 launches forward and 21 backward (17
+# kernels + DistributedDataParallel's four copies of the head's gradients into its buckets): ~0.3 ms of
+# 7-20 us kernels with the chip otherwise idle, at the seam between the forward and the backward pass.  The
+# step runs the SAME arithmetic through coclr_gemm_fused (csrc/nce.hip): the kernel that folds a product's
+# split-K partials also applies the row-level op that follows it, and a weight-gradient product forms the
+# bias gradient as its row sums:
+#   forward   avg-pool | fc1 (+ bias + ReLU) | fc2 (+ bias + F.normalize) | logits            6 launches
+#   backward  dlogits . queue^T (+ l_pos term + F.normalize backward) | . W2 (+ ReLU backward) |
+#             dW2 + db2 | . W1 (+ avg-pool backward) | dW1 + db1                              8 launches
+# Weight and bias gradients are written straight into DistributedDataParallel's bucket views when it has
+# published them (engine.grad_out_for).  Same fold order, same row arithmetic: bit-identical to the module-
+# by-module path (tests/test_gpu_model.py), which COCLR_FUSED_HEAD=0 keeps and which also serves encoders
+# whose head is not the reference's Sequential.  (A first form folded the partials INSIDE the product's
+# launch -- last workgroup of a tile -- and was 2-8x slower per product on MI355X: the device-scope fence
+# every workgroup needs writes back and invalidates L2 across the eight XCDs, and one workgroup folds a
+# whole tile; profiles/r05_head_probe_lastblock.txt.)
+FUSED_HEAD = os.environ.get("COCLR_FUSED_HEAD", "1") != "0"
+
+
+def _head_parts(encoder, dim):
+    """(fc1, fc2) when `encoder` is the reference's nn.Sequential(backbone, AdaptiveAvgPool3d((1,1,1)),
+    Conv3d 1x1x1, ReLU, Conv3d 1x1x1 -> dim) built from this module's classes; else None."""
+    ent = encoder.__dict__.get("_coclr_head_parts")
+    if ent is None:
+        ok = isinstance(encoder, nn.Sequential) and len(encoder) == 5 and \
+            isinstance(encoder[1], GlobalAvgPool3d) and tuple(encoder[1].output_size) == (1, 1, 1) and \
+            isinstance(encoder[2], PointwiseConv3d) and isinstance(encoder[3], HeadReLU) and \
+            isinstance(encoder[4], PointwiseConv3d) and \
+            all(tuple(c.kernel_size) == (1, 1, 1) and c.bias is not None and c.groups == 1
+                for c in (encoder[2], encoder[4])) and \
+            encoder[2].out_channels == encoder[4].in_channels and encoder[4].out_channels == dim and dim <= 128
+        ent = encoder.__dict__["_coclr_head_parts"] = (encoder[2], encoder[4]) if ok else False
+    return ent or None
+
+
+def _fc_splits(M, N, K):
+    """split-K so that a skinny product (M = batch) still fills the chip (see _gemm_auto)"""
+    tiles = ((N + 127) // 128) * ((M + 31) // 32)
+    return max(1, min(K // 32, 256 // tiles))
+
+
+def _head_forward(feat, w1, b1, w2, b2, eps=1e-12):
+    """feature map (N, Cf, T, H, W) -> (q, inv_norm, h0, h1): pooled features, hidden activations and the
+    L2-normalised projection (ref :49-54,153-154), five launches."""
+    feat = feat.contiguous()
+    N_, Cf = feat.shape[0], feat.shape[1]
+    Ch, D = w1.shape[0], w2.shape[0]
+    dev = feat.device
+    h0 = torch.empty(N_, Cf, dtype=feat.dtype, device=dev)
+    ops.global_avgpool_fwd(feat, h0.view(N_, Cf, 1, 1, 1))
+    h1 = torch.empty(N_, Ch, dtype=feat.dtype, device=dev)
+    s1 = _fc_splits(N_, Ch, Cf)
+    ws = torch.empty(ops.gemm_fused_workspace(N_, Ch, Cf, s1), dtype=feat.dtype, device=dev)
+    ops.gemm_fused(h0, Cf, 1, w1.reshape(Ch, Cf), 1, Cf, h1, Ch, b1, N_, Ch, Cf, relu=True, splits=s1,
+                   workspace=ws, mode=0)
+    q = torch.empty(N_, D, dtype=feat.dtype, device=dev)
+    inv = torch.empty(N_, dtype=feat.dtype, device=dev)
+    s2 = _fc_splits(N_, D, Ch)
+    ws2 = torch.empty(ops.gemm_fused_workspace(N_, D, Ch, s2), dtype=feat.dtype, device=dev)
+    ops.gemm_fused(h1, Ch, 1, w2.reshape(D, Ch), 1, Ch, q, D, b2, N_, D, Ch, splits=s2, workspace=ws2,
+                   mode=2, out2=inv, f=eps)
+    return q, inv, h0, h1
+
+
+class _QueryHeadFn(torch.autograd.Function):
+    """feature map of the query encoder -> logits [<q,k> | q . queue] / T, with the gradient to the feature
+    map and the head's parameters (ref :49-54,153-155,175-182 and their autograd backward)."""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, w2, b2, k, queue, T, join):
+        q, inv, h0, h1 = _head_forward(feat, w1, b1, w2, b2)
+        if _engine.DECISION_PROBE is not None:
+            _engine.DECISION_PROBE("relu", "head", (h1 > 0).view(h1.shape[0], h1.shape[1], 1, 1, 1))
+        join()                                    # the keys come from the key stream
+        B, D = q.shape
+        K = queue.shape[1]
+        logits = torch.empty(B, 1 + K, dtype=q.dtype, device=q.device)
+        ops.nce_logits_fwd(q, k, queue, logits, T)
+        # the enqueue that follows overwrites columns of `queue` in place
+        ctx.save_for_backward(h0, h1, q, inv, k, queue.clone(), w1, w2)
+        ctx.T, ctx.fshape = T, tuple(feat.shape)
+        ctx.params = (w1, b1, w2, b2)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        h0, h1, q, inv, k, queue, w1, w2 = ctx.saved_tensors
+        w1p, b1p, w2p, b2p = ctx.params
+        B, D = q.shape
+        K = queue.shape[1]
+        Cf, Ch = h0.shape[1], h1.shape[1]
+        dev, dt = q.device, q.dtype
+        dl = dlogits.contiguous()
+        inv_T = 1.0 / ctx.T
+        # d(un-normalised projection): dlogits[:, 1:] . queue^T / T + the l_pos term, through F.normalize
+        sp = max(1, min(K // 128, 256))
+        ws = torch.empty(ops.gemm_fused_workspace(B, D, K, sp), dtype=dt, device=dev)
+        df = torch.empty(B, D, dtype=dt, device=dev)
+        ops.gemm_fused(dl[:, 1:], 1 + K, 1, queue, 1, K, df, D, None, B, D, K, alpha=inv_T, splits=sp,
+                       workspace=ws, mode=3, ep_a=dl, lda=1 + K, ep_b=k, ep_y=q, inv_norm=inv, f=inv_T)
+        need = ctx.needs_input_grad
+        dw1 = db1 = dw2 = db2 = dx = None
+        # fc2: d(hidden) with the ReLU's backward, weight gradient with the bias gradient as its row sums
+        sp = _fc_splits(B, Ch, D)
+        ws = torch.empty(ops.gemm_fused_workspace(B, Ch, D, sp), dtype=dt, device=dev)
+        dh1 = torch.empty(B, Ch, dtype=dt, device=dev)
+        ops.gemm_fused(df, D, 1, w2.reshape(D, Ch), Ch, 1, dh1, Ch, None, B, Ch, D, splits=sp, workspace=ws,
+                       mode=1, ep_a=h1, lda=Ch)
+        if need[3] or need[4]:
+            dw2 = _engine.grad_out_for(w2p)
+            db2 = _engine.grad_out_for(b2p)
+            ops.gemm_fused(df, 1, D, h1, Ch, 1, dw2, Ch, None, D, Ch, B, rowsum=db2)
+        # fc1: d(feature map) through the average pool, weight gradient + bias gradient
+        if need[0]:
+            S = 1
+            for v in ctx.fshape[2:]:
+                S *= v
+            sp = _fc_splits(B, Cf, Ch)
+            ws = torch.empty(ops.gemm_fused_workspace(B, Cf, Ch, sp), dtype=dt, device=dev)
+            dx = torch.empty(ctx.fshape, dtype=dt, device=dev)
+            ops.gemm_fused(dh1, Ch, 1, w1.reshape(Ch, Cf), Cf, 1, dx, 0, None, B, Cf, Ch, splits=sp,
+                           workspace=ws, mode=4, S=S)
+        if need[1] or need[2]:
+            dw1 = _engine.grad_out_for(w1p)
+            db1 = _engine.grad_out_for(b1p)
+            ops.gemm_fused(dh1, 1, Ch, h0, Cf, 1, dw1, Cf, None, Ch, Cf, B, rowsum=db1)
+        return dx, dw1, db1, dw2, db2, None, None, None, None
+
+
 def _make_encoder(network, dim):
     backbone, param = select_backbone(network)
     fs = param["feature_size"]
@@ -613,6 +745,12 @@ class InfoNCE(nn.Module):
     def _encode(self, encoder, x, n_index=None):
         """encoder(x) -> L2-normalised (B, dim); x may be a strided clip view."""
         feat = encoder[0](x, n_index=n_index) if n_index is not None else encoder[0](x)
+        parts = _head_parts(encoder, self.dim) if FUSED_HEAD else None
+        if parts is not None and not (torch.is_grad_enabled() and (
+                feat.requires_grad or any(p.requires_grad for p in encoder[2].parameters()) or
+                any(p.requires_grad for p in encoder[4].parameters()))):
+            fc1, fc2 = parts
+            return _head_forward(feat, fc1.weight, fc1.bias, fc2.weight, fc2.bias)[0]
         for mod in list(encoder)[1:]:
             feat = mod(feat)
         return _L2NormFn.apply(feat.view(feat.shape[0], self.dim))
@@ -864,6 +1002,21 @@ class InfoNCE(nn.Module):
         ops.gather_rows(k_all_shuf.contiguous(), idx_unshuffle.contiguous(), k_all)
         return k_all[rank * B:(rank + 1) * B], k_all
 
+    def _query_logits(self, x1, k, side, in_train_mode):
+        """q = normalize(encoder_q(x1)); logits = [<q,k> | q . queue] / T (ref :153-155,175-182)."""
+        parts = _head_parts(self.encoder_q, self.dim) if FUSED_HEAD else None
+        if parts is None or not in_train_mode:
+            q = self._encode(self.encoder_q, x1)
+            assert q.requires_grad == in_train_mode
+            self._join(side)
+            return _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
+        fc1, fc2 = parts
+        feat = self.encoder_q[0](x1)
+        logits = _QueryHeadFn.apply(feat, fc1.weight, fc1.bias, fc2.weight, fc2.bias, k.contiguous(),
+                                    self.queue, float(self.T), lambda: self._join(side))
+        assert logits.requires_grad
+        return logits
+
     def _split_pair(self, block):
         (B, N, *_) = block.shape  # [B,N,C,T,H,W]
         assert N == 2
@@ -882,11 +1035,7 @@ class InfoNCE(nn.Module):
         with torch.no_grad(), torch.cuda.stream(side):
             k, k_all = self._encode_keys(
                 x2, pre=self._momentum_pre(in_train_mode))
-        q = self._encode(self.encoder_q, x1)
-        assert q.requires_grad == in_train_mode
-        self._join(side)
-
-        logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
+        logits = self._query_logits(x1, k, side, in_train_mode)
         labels = torch.zeros(B, dtype=torch.long, device=logits.device)
 
         if in_train_mode:
@@ -923,11 +1072,7 @@ class UberNCE(InfoNCE):
         with torch.no_grad(), torch.cuda.stream(side):
             k, k_all = self._encode_keys(
                 x2, pre=self._momentum_pre(in_train_mode))
-        q = self._encode(self.encoder_q, x1)
-        assert q.requires_grad == in_train_mode
-        self._join(side)
-
-        logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
+        logits = self._query_logits(x1, k, side, in_train_mode)
 
         # mask[:,0] = True, mask[:,1+j] = (k_label == queue_label[j])   (ref :267-269)
         k_label = k_label.to(device=logits.device, dtype=torch.long).contiguous()
@@ -998,11 +1143,7 @@ class CoCLR(InfoNCE):
             if ident is None or ident.shape[0] != B or ident.device != f2.device:
                 ident = self.__dict__["_ident_idx"] = torch.arange(B, device=f2.device)
             kf = self._encode_graphed(self.sampler, f2, ident)
-        q = self._encode(self.encoder_q, x1)
-        assert q.requires_grad == in_train_mode
-        self._join(side)
-
-        logits = _NceLogitsFn.apply(q, k.contiguous(), self.queue, float(self.T))
+        logits = self._query_logits(x1, k, side, in_train_mode)
 
         k_vsource = k_vsource.to(device=logits.device, dtype=torch.long).contiguous()
         if not self.queue_is_full:

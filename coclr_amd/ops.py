@@ -587,6 +587,24 @@ def gemm(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha=1.0, relu=False,
         int(accumulate), splits, _p(workspace), _stream()), "gemm")
 
 
+def gemm_fused_workspace(M, N, K, splits):
+    return M * N * max(1, splits)
+
+
+def gemm_fused(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha=1.0, relu=False, splits=1,
+               workspace=None, mode=0, S=0, ep_a=None, lda=0, ep_b=None, ep_y=None, inv_norm=None, out2=None,
+               f=0.0, rowsum=None):
+    """coclr_gemm_fused (include/coclr_hip.h): the product with the row-level operation that follows it
+    (mode 1 ReLU backward, 2 row normalise, 3 l_pos + normalise backward, 4 average-pool backward) applied
+    by the kernel that folds the split-K partials; mode 0 with splits 1 is the plain product in one launch
+    (optionally + row sums of A)."""
+    ep = _lib.GemmEpilogue(int(mode), int(S), _p(ep_a), int(lda), _p(ep_b), _p(ep_y), _p(inv_norm), _p(out2),
+                           float(f), _p(rowsum))
+    _lib.check(_L().coclr_gemm_fused(
+        _p(a), sam, sak, _p(b), sbk, sbn, _p(c), ldc, _p(bias), M, N, K, alpha, int(relu), splits,
+        _p(workspace), C.byref(ep), _stream()), "gemm_fused")
+
+
 def l2norm_fwd(x, y, inv_norm, eps=1e-12):
     rows, D = x.shape
     _lib.check(_L().coclr_l2norm_fwd(_p(x), _p(y), _p(inv_norm), rows, D, eps, _stream()),

@@ -308,6 +308,35 @@ int coclr_gemm(const float* a, int64_t sam, int64_t sak, const float* b, int64_t
                float* c, int64_t ldc, const float* bias, int M, int N, int K, float alpha, int relu,
                int accumulate, int splits, float* workspace, void* stream);
 
+/* The products of an encoder's projection head and of its backward, each with the row-level operation
+ * that FOLLOWS it in the reference applied by the kernel that folds the split-K partials
+ * (pretrain.py:49-54: AdaptiveAvgPool3d -> Conv3d 1x1x1 -> ReLU -> Conv3d 1x1x1; :153-154 / :166-167
+ * F.normalize; :175-182 the logits whose gradient arrives here).  Two launches per product instead of three
+ * or four, same fold order as coclr_gemm (k = 0 .. splits-1: bit-identical to the unfused sequence):
+ *   mode 0  none (with splits == 1: the plain product in one launch, optionally + rowsum)
+ *   mode 1  aten::threshold_backward: c = a[m][n] > 0 ? v : 0            (nn.ReLU backward, pretrain.py:53)
+ *   mode 2  F.normalize rows: c = v / max(||v||, f), out2[m] = 1 / max(||v||, f)              (N <= 512)
+ *   mode 3  v += a[m*lda] * f * b[m][n]  (the l_pos term of pretrain.py:175, f = 1/T), then the backward of
+ *           F.normalize: c = (v - y <y, v>) * inv_norm[m]                                      (N <= 512)
+ *   mode 4  aten::adaptive_avg_pool3d backward: c is dense [M][N][S], c[m][n][:] = v / S
+ * rowsum (splits == 1): rowsum[m] = sum_k A(m,k) -- the bias gradient of a weight-gradient product.
+ * workspace: max(splits, 1) * M * N elements (always used unless mode 0 with splits == 1). */
+typedef struct coclr_gemm_epilogue {
+  int32_t mode;
+  int32_t S;
+  const float* a;
+  int64_t lda;
+  const float* b;
+  const float* y;
+  const float* inv_norm;
+  float* out2;
+  float f;
+  float* rowsum;
+} coclr_gemm_epilogue;
+int coclr_gemm_fused(const float* a, int64_t sam, int64_t sak, const float* b, int64_t sbk, int64_t sbn,
+                     float* c, int64_t ldc, const float* bias, int M, int N, int K, float alpha, int relu,
+                     int splits, float* workspace, const coclr_gemm_epilogue* ep, void* stream);
+
 /* F.normalize(x, dim=1) over rows of D (pretrain.py:154,167,380) and backward. */
 int coclr_l2norm_fwd(const float* x, float* y, float* inv_norm, int rows, int D, float eps,
                      void* stream);

@@ -334,6 +334,40 @@ def gemm(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha=1.0, relu=False,
         dst.copy_(v)
 
 
+def gemm_fused_workspace(M, N, K, splits):
+    return M * N * max(1, splits)
+
+
+def gemm_fused(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha=1.0, relu=False, splits=1,
+               workspace=None, mode=0, S=0, ep_a=None, lda=0, ep_b=None, ep_y=None, inv_norm=None, out2=None,
+               f=0.0, rowsum=None):
+    A = torch.as_strided(a, (M, K), (sam, sak))
+    Bm = torch.as_strided(b, (K, N), (sbk, sbn))
+    v = alpha * (A @ Bm)
+    if bias is not None:
+        v = v + bias
+    if relu:
+        v = torch.relu(v)
+    if rowsum is not None:
+        rowsum.reshape(-1).copy_(A.sum(1))
+    if mode == 1:
+        v = v * (torch.as_strided(ep_a, (M, N), (lda, 1)) > 0)
+    elif mode == 2:
+        inv = 1.0 / v.norm(dim=1).clamp_min(f)
+        if out2 is not None:
+            out2.copy_(inv)
+        v = v * inv[:, None]
+    elif mode == 3:
+        v = v + torch.as_strided(ep_a, (M, 1), (lda, 1)) * f * ep_b
+        dot = (v * ep_y).sum(1, keepdim=True)
+        v = (v - ep_y * dot) * inv_norm[:, None]
+    elif mode == 4:
+        c.reshape(M, N, S).copy_((v / S)[:, :, None].expand(M, N, S))
+        return
+    c.reshape(-1)[:0]          # (c may be a 5-d parameter-shaped gradient: written through its flat memory)
+    torch.as_strided(c, (M, N), (ldc, 1)).copy_(v)
+
+
 def l2norm_fwd(x, y, inv_norm, eps=1e-12):
     inv = 1.0 / x.norm(dim=1).clamp_min(eps)
     y.copy_(x * inv[:, None])

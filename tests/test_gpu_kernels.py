@@ -453,6 +453,81 @@ def test_gemm_layouts(M, N, K, ta, tb, splits):
     close(c, ref, what="gemm")
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(32, 1024, 1024, 32), (8, 1024, 128, 4), (32, 128, 1024, 32),
+                                          (5, 100, 70, 2), (32, 2048, 2048, 16)])
+def test_gemm_fused_fold_is_the_two_launch_fold(M, N, K, splits):
+    """coclr_gemm_fused folds its split-K partials in the order coclr_gemm does: bit-identical, run after run."""
+    from coclr_amd import ops
+    torch.manual_seed(17)
+    A, Bm, bias = dev(torch.randn(M, K)), dev(torch.randn(N, K)), dev(torch.randn(N))
+    ref = torch.empty(M, N, device="cuda")
+    ws = torch.empty(max(1, ops.gemm_workspace(M, N, K, splits)), device="cuda")
+    ops.gemm(A, K, 1, Bm, 1, K, ref, N, bias, M, N, K, alpha=0.5, relu=True, splits=splits, workspace=ws)
+    for _ in range(3):
+        got = torch.full((M, N), float("nan"), device="cuda")
+        ws2 = torch.empty(ops.gemm_fused_workspace(M, N, K, splits), device="cuda")
+        ops.gemm_fused(A, K, 1, Bm, 1, K, got, N, bias, M, N, K, alpha=0.5, relu=True, splits=splits,
+                       workspace=ws2)
+        assert torch.equal(got, ref)
+    close(ref, torch.relu(0.5 * (A.double() @ Bm.double().t()).float() + bias), what="gemm")
+
+
+def test_gemm_fused_epilogues():
+    """The row-level epilogues of the projection head (model/pretrain.py:49-54,153-154,175-182 and their
+    backward) against ATen: ReLU backward, F.normalize, l_pos + F.normalize backward, average-pool backward,
+    and the bias gradient as the row sums of a weight-gradient product."""
+    from coclr_amd import ops
+    torch.manual_seed(18)
+    B, D, C_, K, T, S = 6, 128, 200, 640, 0.07, 12
+
+    def fused(A, Bkn, M, N, Kd, splits, c=None, **kw):
+        c = torch.empty(M, N, device="cuda") if c is None else c
+        ws = torch.empty(ops.gemm_fused_workspace(M, N, Kd, splits), device="cuda")
+        ops.gemm_fused(A, A.stride(0), A.stride(1), Bkn, Bkn.stride(0), Bkn.stride(1), c, N, None, M, N, Kd,
+                       splits=splits, workspace=ws, **kw)
+        return c
+
+    # mode 1: (dy . W) masked by the ReLU's output
+    dy, W, h = torch.randn(B, D), torch.randn(D, C_), torch.randn(B, C_)
+    got = fused(dev(dy), dev(W), B, C_, D, 4, mode=1, ep_a=dev(h), lda=C_)
+    close(got, (dy @ W) * (h > 0), what="relu backward epilogue")
+    # mode 2: F.normalize of the product's rows
+    x, W2 = torch.randn(B, C_), torch.randn(D, C_)
+    inv = torch.empty(B, device="cuda")
+    got = fused(dev(x), dev(W2).t(), B, D, C_, 3, mode=2, out2=inv, f=1e-12)
+    y = x @ W2.t()
+    close(got, F.normalize(y, dim=1), what="normalize epilogue")
+    close(inv, 1 / y.norm(dim=1), what="inverse norms")
+    # mode 3: logits backward (queue term + l_pos term) through F.normalize
+    xq = torch.randn(B, D, requires_grad=True)
+    q = F.normalize(xq, dim=1)
+    k = F.normalize(torch.randn(B, D), dim=1)
+    queue = F.normalize(torch.randn(D, K), dim=0)
+    logits = torch.cat([(q * k).sum(1, keepdim=True), q @ queue], 1) / T
+    dl = torch.randn_like(logits)
+    logits.backward(dl)
+    dld = dev(dl)
+    invq = dev(1 / xq.detach().norm(dim=1))
+    got = torch.empty(B, D, device="cuda")
+    ws = torch.empty(ops.gemm_fused_workspace(B, D, K, 5), device="cuda")
+    queued = dev(queue)
+    ops.gemm_fused(dld[:, 1:], 1 + K, 1, queued, 1, K, got, D, None, B, D, K, alpha=1 / T, splits=5, workspace=ws,
+                   mode=3, ep_a=dld, lda=1 + K, ep_b=dev(k), ep_y=dev(q.detach()), inv_norm=invq, f=1 / T)
+    close(got, xq.grad, what="logits + normalize backward epilogue")
+    # mode 4: the product spread over planes of S positions
+    dh, W1 = torch.randn(B, D), torch.randn(D, C_)
+    dx = torch.empty(B, C_, 2, 3, 2, device="cuda")
+    fused(dev(dh), dev(W1), B, C_, D, 2, c=dx, mode=4, S=S)
+    close(dx, ((dh @ W1) / S)[:, :, None, None, None].expand(B, C_, 2, 3, 2), what="average-pool backward epilogue")
+    # weight gradient + bias gradient (row sums of A) in one launch, no split
+    dyo, xin = torch.randn(B, D), torch.randn(B, C_)
+    dw, db = torch.empty(D, C_, device="cuda"), torch.empty(D, device="cuda")
+    dyd, xd = dev(dyo), dev(xin)
+    ops.gemm_fused(dyd, 1, D, xd, C_, 1, dw, C_, None, D, C_, B, rowsum=db)
+    close(dw, dyo.t() @ xin, what="weight gradient")
+    close(db, dyo.sum(0), what="bias gradient")
+
+
 def test_l2norm_and_logits():
     from coclr_amd import ops
     torch.manual_seed(8)
