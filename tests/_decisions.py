@@ -76,6 +76,9 @@ class _FProxy:
         self.dec = Decisions()
         self.cur = None
         self.ip = 0
+        # force mode: decisions the oracle's OWN arithmetic would have taken differently at this unit, given the
+        # same (forced) decisions everywhere upstream -- [(what, differing, of)]
+        self.disagree = []
 
     def __getattr__(self, name):
         return getattr(F, name)
@@ -86,7 +89,11 @@ class _FProxy:
         # a ReLU that does not follow a BatchNorm is the projection head's (model/pretrain.py:53)
         name, self.cur = (self.cur or "head"), None
         if self.force is not None:
-            return x * self.force.relu[name].to(x.dtype)
+            m = self.force.relu[name]
+            d = int(((x.detach() > 0) != m).sum())
+            if d:
+                self.disagree.append((name, d, m.numel()))
+            return x * m.to(x.dtype)
         self.dec.relu[name] = x.detach() > 0
         return F.relu(x)
 
@@ -97,7 +104,13 @@ class _FProxy:
             idx = self.force.pools[self.ip]
             self.ip += 1
             n, c = x.shape[:2]
-            return x.reshape(n, c, -1).gather(2, idx.reshape(n, c, -1)).reshape(idx.shape)
+            picked = x.reshape(n, c, -1).gather(2, idx.reshape(n, c, -1)).reshape(idx.shape)
+            # a different arg-max only counts when it selects a different VALUE (ties are the same decision)
+            own = F.max_pool3d(x.detach(), k, s, p)
+            d = int((own != picked.detach()).sum())
+            if d:
+                self.disagree.append(("pool#%d" % (self.ip - 1), d, idx.numel()))
+            return picked
         out, idx = F.max_pool3d(x, k, s, p, return_indices=True)
         self.dec.pools.append(idx)
         return out
@@ -138,6 +151,7 @@ def oracle_grads(state_dict, cfg, blocks, extra, perm, dtype=torch.float32, deci
             continue
         seen.add(v.data_ptr())
         grads[k] = v.grad
+    proxy.dec.disagree = proxy.disagree
     return grads, loss.detach(), logits.detach(), proxy.dec
 
 

@@ -56,8 +56,11 @@ def test_caller_sequence_on_gpu_matches_reference_scripts(name, tmp_path):
             assert abs(rec["losses"][i] - gold["losses"][i]) <= 5e-3 * max(1.0, abs(gold["losses"][i]))
         else:
             # after an Adam step at initialisation no build follows the reference's trajectory tightly
-            # (tests/test_host_cpu.py explains); same ball park, same shapes
-            check_close(rec["outputs"][i], gold["outputs"][i], 0.25, "logits of iteration %d" % i)
+            # (tests/test_host_cpu.py explains): this bar is SHAPE / BALL PARK ONLY -- the parity of an
+            # iteration that starts from updated weights is held at 1e-3 against the oracle continued from the
+            # product's own state (tests/test_gpu_model.py::_replay, step 2)
+            check_close(rec["outputs"][i], gold["outputs"][i], 0.25,
+                        "logits of iteration %d (ball-park bar only, see the comment above)" % i)
     # what the script would checkpoint (main_nce.py:278-290): reference keys, loadable by torch.save/load
     model, opt = rec["model"], rec["optimizer"]
     sd = model.state_dict()

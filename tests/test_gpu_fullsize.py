@@ -375,3 +375,54 @@ def test_config2_training_step_matches_oracle():
     g = model.encoder_q[4].weight.grad
     rg = ref_sd["encoder_q.4.weight"].grad
     check_close(g, rg, 5e-3, "head weight gradient")
+
+
+def test_ubernce_training_step_at_config2_size():
+    """UberNCE (model/pretrain.py:193-278, the supervised variant main_nce.py:318-324 trains) at BASELINE
+    config 2's size -- B=32 clips of 3x32x128x128, K=2048 -- against the CPU oracle: logits at the north star's
+    1e-3, the positive mask (col 0 | k_label == queue_label) and the label queue EXACT, pointer exact, enqueued
+    keys and the head's weight gradient under the loss of main_nce.py:318-320.  The label queue is pre-filled
+    (51 classes, a stretch still -1) so that the mask has real positives."""
+    import os
+    import model.pretrain as product
+    from oracle import coclr_oracle as orc
+    from _cases import check_close, loss_fn
+    K, ncls = 2048, 51
+    torch.manual_seed(0)
+    model = product.UberNCE('s3d', 128, K, 0.999, 0.07)
+    g = torch.Generator().manual_seed(3)
+    model.queue_label.copy_(torch.randint(0, ncls, (K,), generator=g))
+    model.queue_label[K - 200:] = -1
+    ref_sd = orc.training_state(model.state_dict())
+    model = model.cuda().train()
+    torch.manual_seed(1)
+    block = torch.randn(B, 2, 3, 32, 128, 128)
+    k_label = torch.randint(0, ncls, (B,), generator=g)
+    torch.manual_seed(2)
+    perm = torch.randperm(B)
+    torch.manual_seed(2)
+    logits, mask = model(block.cuda(), k_label.cuda())
+    loss = loss_fn("ubernce", logits, mask)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    try:
+        (ref_logits, ref_mask), = orc.nce_step(ref_sd, "ubernce", "s3d", [block], [k_label], 128, K, 0.999, 0.07,
+                                               perm)
+        ref_loss = loss_fn("ubernce", ref_logits, ref_mask)
+        ref_loss.backward()
+    finally:
+        torch.set_num_threads(threads)
+    check_close(logits, ref_logits, 1e-3, "logits")
+    assert mask.dtype == torch.bool and torch.equal(mask.cpu(), ref_mask.bool())
+    assert int(mask[:, 1:].sum()) > B, "the pre-filled label queue should give every row positives"
+    assert abs(float(loss) - float(ref_loss)) <= 1e-3 * max(1.0, abs(float(ref_loss)))
+    sd = model.state_dict()
+    assert int(sd["queue_ptr"]) == int(ref_sd["queue_ptr"]) == B
+    assert torch.equal(sd["queue_label"].cpu(), ref_sd["queue_label"])
+    assert torch.equal(sd["queue_label"][:B].cpu(), k_label)
+    check_close(sd["queue"][:, :B], ref_sd["queue"][:, :B], 1e-3, "enqueued keys")
+    assert torch.equal(sd["queue"][:, B:].cpu(), ref_sd["queue"][:, B:])
+    check_close(model.encoder_q[4].weight.grad, ref_sd["encoder_q.4.weight"].grad, 5e-3, "head weight gradient")
