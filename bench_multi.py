@@ -377,7 +377,10 @@ def next_rung(rung, statuses):
 
 def supervise(argv, hang_timeout):
     """Layer 1.  Returns the process exit code."""
+    import signal
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, _on_term)
     store = _store()
     pre = "coclr_bench/%s/" % os.environ.get("TORCHELASTIC_RUN_ID", "run")
     rung = int(os.environ.get("COCLR_BENCH_RUNG", "0"))
@@ -396,7 +399,8 @@ def supervise(argv, hang_timeout):
         env = dict(os.environ, COCLR_BENCH_CHILD="1", COCLR_BENCH_DIR=adir,
                    COCLR_BENCH_INIT="file://" + os.path.join(adir, "rendezvous"), **rung_env(rung))
         child = subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + argv, env=env,
-                                 stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
+                                 stdout=subprocess.PIPE, stderr=None, text=True, preexec_fn=_child_preexec)
+        _CHILDREN.append(child)
         # the child's own watchdog ends a hang after `hang_timeout` without progress; this limit is the
         # backstop for a child that cannot even do that
         limit = time.monotonic() + float(os.environ.get("COCLR_BENCH_ATTEMPT_LIMIT", 8 * hang_timeout + 900))
@@ -495,8 +499,30 @@ def supervise(argv, hang_timeout):
     return 0 if succeeded else 1
 
 
+_CHILDREN = []
+
+
+def _child_preexec():
+    """The measuring process gets its own process group (so that exactly it and what it starts can be ended)
+    and dies with its supervisor: a launcher that is killed (driver timeout) must not leave a rank on a GPU."""
+    os.setsid()
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)   # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
+def _on_term(signum, frame):
+    for c in _CHILDREN:
+        if c.poll() is None:
+            _kill(c)
+    os._exit(128 + signum)
+
+
 def _kill(child):
-    """End exactly the process group this supervisor started (start_new_session above)."""
+    """End exactly the process group this supervisor started (os.setsid in _child_preexec)."""
     import signal
     try:
         os.killpg(child.pid, signal.SIGKILL)
