@@ -302,7 +302,10 @@ def cpu_baseline(args):
             "kind": "port",
             "sample": "%d timed steps (1 warm-up) of S3D InfoNCE K=2048 B=4 3x%dx%dx%d fwd+bwd+Adam "
                       "through oracle/coclr_oracle.py (the reference's ATen CPU kernels) on %d of "
-                      "this host's %d hardware threads, %.2f s/step"
+                      "this host's %d hardware threads, %.2f s/step; the port against the reference's OWN "
+                      "module on one host, alternating, same threads: time ratio 1.010, identical losses "
+                      "(profiles/r05_cpu_port_vs_reference.txt, tools/cpu_port_vs_reference.py -- the "
+                      "reference itself does not exist on the GPU box)"
                       % (len(times), args.seq_len, args.img_dim, args.img_dim,
                          torch.get_num_threads(), os.cpu_count() or 0, dt)}
 
@@ -338,7 +341,7 @@ def nce_roofline(device, B):
            "algorithmic_mb_per_launch": round(byts / 1e6, 2),
            "tflops": round(flop / us / 1e6, 2),
            "mfma_frac_of_fp32_peak": round(flop / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 4)}
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         pj = os.path.join(ROOT, "profiles", tag + "_nce_pmc.json")
         if os.path.exists(pj):
             rec["pmc"] = json.load(open(pj))
@@ -373,7 +376,15 @@ def main():
             os.environ.get("COCLR_BENCH_LADDER", "1") != "0":
         # the ranks the driver starts supervise; the measuring processes are their children
         import bench_multi
-        sys.exit(bench_multi.supervise(sys.argv[1:], args.hang_timeout))
+        try:
+            store = bench_multi._store()
+        except Exception as e:
+            # no store to agree over (a launcher without one): measure in this process, without the ladder
+            print("bench: supervisors cannot reach the launcher's store (%s); running without the process "
+                  "ladder" % e, file=sys.stderr, flush=True)
+            store = None
+        if store is not None:
+            sys.exit(bench_multi.supervise(sys.argv[1:], args.hang_timeout, store))
     try:
         measure(args, world)
     except SystemExit:

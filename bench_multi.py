@@ -357,6 +357,16 @@ def _store():
                          timeout=datetime.timedelta(seconds=600), wait_for_workers=False)
 
 
+def _wait_keys(store, keys, seconds):
+    """store.wait without its fixed timeout: poll until every key is there (True) or `seconds` have passed."""
+    end = time.monotonic() + seconds
+    while time.monotonic() < end:
+        if store.check(list(keys)):
+            return True
+        time.sleep(0.25)
+    return False
+
+
 def next_rung(rung, statuses):
     """Where the next attempt starts, from what the failed one left behind.  A failure that names the
     exchange it happened in drops to the rung that removes that exchange; an unattributed one first gives up
@@ -375,13 +385,14 @@ def next_rung(rung, statuses):
     return max(want, rung + 1) if rung < SERIAL else None
 
 
-def supervise(argv, hang_timeout):
+def supervise(argv, hang_timeout, store=None):
     """Layer 1.  Returns the process exit code."""
     import signal
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sig, _on_term)
-    store = _store()
+    if store is None:
+        store = _store()
     pre = "coclr_bench/%s/" % os.environ.get("TORCHELASTIC_RUN_ID", "run")
     rung = int(os.environ.get("COCLR_BENCH_RUNG", "0"))
     attempts = []
@@ -394,7 +405,8 @@ def supervise(argv, hang_timeout):
             adir = tempfile.mkdtemp(prefix="coclr_bench_a%d_" % attempt)
             store.set(pre + "%d/dir" % attempt, adir)
         else:
-            store.wait([pre + "%d/dir" % attempt])
+            if not _wait_keys(store, [pre + "%d/dir" % attempt], 1800):
+                raise RuntimeError("bench supervisor: rank 0's supervisor never opened attempt %d" % attempt)
             adir = store.get(pre + "%d/dir" % attempt).decode()
         env = dict(os.environ, COCLR_BENCH_CHILD="1", COCLR_BENCH_DIR=adir,
                    COCLR_BENCH_INIT="file://" + os.path.join(adir, "rendezvous"), **rung_env(rung))
@@ -443,8 +455,11 @@ def supervise(argv, hang_timeout):
             elif ln.strip():
                 print(ln, file=sys.stderr)             # RCCL's banner etc.: never on the supervisor's stdout
         store.set(keys[rank], json.dumps(status))
-        store.wait(keys)
-        statuses = [json.loads(store.get(k).decode()) for k in keys]
+        # every supervisor reports within the attempt limit (a child cannot outlive it); peers that do not are
+        # counted as failed rather than waited for forever
+        _wait_keys(store, keys, float(os.environ.get("COCLR_BENCH_ATTEMPT_LIMIT", 8 * hang_timeout + 900)) + 60)
+        statuses = [json.loads(store.get(k).decode()) if store.check([k]) else
+                    {"rank": r, "rc": -1, "error": "its supervisor did not report"} for r, k in enumerate(keys)]
         ok = all(s["rc"] == 0 for s in statuses)
         rec = None
         if rank == 0:
@@ -455,8 +470,8 @@ def supervise(argv, hang_timeout):
             ok = ok and rec is not None and rec.get("value") is not None
             store.set(pre + "%d/verdict" % attempt, "1" if ok else "0")
         else:
-            store.wait([pre + "%d/verdict" % attempt])
-            ok = store.get(pre + "%d/verdict" % attempt) == b"1"
+            ok = _wait_keys(store, [pre + "%d/verdict" % attempt], 600) and \
+                store.get(pre + "%d/verdict" % attempt) == b"1"
         summary = {"attempt": attempt, "started_on_rung": rung, "rung_name": RUNG_NAMES[rung], "ok": ok,
                    "exit_codes": [s["rc"] for s in statuses]}
         if not ok:
@@ -492,10 +507,7 @@ def supervise(argv, hang_timeout):
     # leave together: the store lives in the launcher (or in rank 0, which therefore leaves last)
     store.set(pre + "done/%d" % rank, "1")
     if rank == 0:
-        try:
-            store.wait([pre + "done/%d" % r for r in range(world)])
-        except Exception:
-            pass
+        _wait_keys(store, [pre + "done/%d" % r for r in range(world)], 120)
     return 0 if succeeded else 1
 
 

@@ -118,11 +118,18 @@ class GlobalAvgPool3d(nn.AdaptiveAvgPool3d):
         return _AvgPoolFn.apply(x)
 
 
+def _fc_splits(M, N, K):
+    """split-K so that a skinny product (M = batch) still fills the chip: a 32 x 1024 x 1024 head layer is 8
+    output tiles.  K slices of at least 64 (profiles/r05_head_probe.txt: 16 splits of a K = 1024 product beat
+    32 -- the fold kernel reads every partial), at most ~256 workgroups."""
+    tiles = ((N + 127) // 128) * ((M + 31) // 32)
+    return max(1, min(K // 64, 256 // tiles))
+
+
 def _gemm_auto(a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K):
     """ops.gemm with split-K sized so a skinny product (M = batch) still fills the chip:
     a 32 x 1024 x 1024 head layer is 8 output tiles -- split K until ~256 workgroups."""
-    tiles = ((N + 127) // 128) * ((M + 31) // 32)
-    splits = max(1, min(K // 32, 256 // tiles))
+    splits = _fc_splits(M, N, K)
     ws = None
     if splits > 1:
         ws = torch.empty(ops.gemm_workspace(M, N, K, splits), dtype=c.dtype, device=c.device)
@@ -241,7 +248,7 @@ class _NceLogitsFn(torch.autograd.Function):
         k, queue = ctx.saved_tensors
         B, D = k.shape
         K = queue.shape[1]
-        splits = max(1, min(K // 128, 256))
+        splits = _logits_bwd_splits(K)
         ws = torch.empty(max(1, ops.gemm_workspace(B, D, K, splits)), dtype=k.dtype,
                          device=k.device)
         dq = torch.empty(B, D, dtype=k.dtype, device=k.device)
@@ -260,7 +267,7 @@ class _NceLogitsFn(torch.autograd.Function):
 # bias gradient as its row sums:
 #   forward   avg-pool | fc1 (+ bias + ReLU) | fc2 (+ bias + F.normalize) | logits            6 launches
 #   backward  dlogits . queue^T (+ l_pos term + F.normalize backward) | . W2 (+ ReLU backward) |
-#             dW2 + db2 | . W1 (+ avg-pool backward) | dW1 + db1                              8 launches
+#             dW2 + db2 | . W1 | avg-pool backward | dW1 + db1                                9 launches
 # Weight and bias gradients are written straight into DistributedDataParallel's bucket views when it has
 # published them (engine.grad_out_for).  Same fold order, same row arithmetic: bit-identical to the module-
 # by-module path (tests/test_gpu_model.py), which COCLR_FUSED_HEAD=0 keeps and which also serves encoders
@@ -287,10 +294,10 @@ def _head_parts(encoder, dim):
     return ent or None
 
 
-def _fc_splits(M, N, K):
-    """split-K so that a skinny product (M = batch) still fills the chip (see _gemm_auto)"""
-    tiles = ((N + 127) // 128) * ((M + 31) // 32)
-    return max(1, min(K // 32, 256 // tiles))
+def _logits_bwd_splits(K):
+    """split count of dlogits . queue^T (measured alone on the chip, profiles/r05_head_probe.txt: K = 2048 is
+    fastest at 32 splits, 21.8 us; K = 16384 at 64, 48.8 us against 60.5 at 128: the fold reads every partial)"""
+    return max(1, min(K // 64, 64))
 
 
 def _head_forward(feat, w1, b1, w2, b2, eps=1e-12):
@@ -347,7 +354,7 @@ class _QueryHeadFn(torch.autograd.Function):
         dl = dlogits.contiguous()
         inv_T = 1.0 / ctx.T
         # d(un-normalised projection): dlogits[:, 1:] . queue^T / T + the l_pos term, through F.normalize
-        sp = max(1, min(K // 128, 256))
+        sp = _logits_bwd_splits(K)
         ws = torch.empty(ops.gemm_fused_workspace(B, D, K, sp), dtype=dt, device=dev)
         df = torch.empty(B, D, dtype=dt, device=dev)
         ops.gemm_fused(dl[:, 1:], 1 + K, 1, queue, 1, K, df, D, None, B, D, K, alpha=inv_T, splits=sp,
@@ -366,14 +373,16 @@ class _QueryHeadFn(torch.autograd.Function):
             ops.gemm_fused(df, 1, D, h1, Ch, 1, dw2, Ch, None, D, Ch, B, rowsum=db2)
         # fc1: d(feature map) through the average pool, weight gradient + bias gradient
         if need[0]:
-            S = 1
-            for v in ctx.fshape[2:]:
-                S *= v
+            # (the fold kernel can spread the values over their planes itself -- mode 4 -- but every one of
+            # the S threads of a plane then reads all the partials: 28.9 us against 15.7 + 7.9 for fold +
+            # average-pool backward as two launches, profiles/r05_head_probe.txt)
             sp = _fc_splits(B, Cf, Ch)
             ws = torch.empty(ops.gemm_fused_workspace(B, Cf, Ch, sp), dtype=dt, device=dev)
+            dh0 = torch.empty(B, Cf, 1, 1, 1, dtype=dt, device=dev)
+            ops.gemm_fused(dh1, Ch, 1, w1.reshape(Ch, Cf), Cf, 1, dh0, Cf, None, B, Cf, Ch, splits=sp,
+                           workspace=ws)
             dx = torch.empty(ctx.fshape, dtype=dt, device=dev)
-            ops.gemm_fused(dh1, Ch, 1, w1.reshape(Ch, Cf), Cf, 1, dx, 0, None, B, Cf, Ch, splits=sp,
-                           workspace=ws, mode=4, S=S)
+            ops.global_avgpool_bwd(dh0, dx)
         if need[1] or need[2]:
             dw1 = _engine.grad_out_for(w1p)
             db1 = _engine.grad_out_for(b1p)
