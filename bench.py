@@ -497,8 +497,10 @@ def measure(args, world):
     def make_ddp(hook):
         hook = bool(hook)
         if hook not in wrappers:
+            # NOT `.train()` on the new wrapper: that would walk into the model and put CoCLR's frozen sampler
+            # (eval mode, main_coclr.py:363) back into training mode -- which is how the self-check's first run
+            # on CoCLR failed: the step before the second wrapper existed differed from every step after it
             wrappers[hook] = wrap(model, hook)
-            wrappers[hook].train()
         return wrappers[hook]
 
     ddp = make_ddp(switches.wants_hook(rung))
@@ -507,6 +509,7 @@ def measure(args, world):
     opt = torch.optim.Adam(groups, lr=1e-3, weight_decay=1e-5)
     assert isinstance(opt, NativeAdam), "the model.pretrain shim should have resolved torch.optim.Adam"
     criterion = L.CrossEntropyLoss()
+    ddp.train()
     if args.model == "coclr":
         model.sampler.eval()
 
@@ -725,6 +728,8 @@ def measure(args, world):
         model16 = build(16384)
         ddp16 = wrap(model16)
         ddp16.train()
+        if args.model == "coclr":
+            model16.sampler.eval()
         opt16 = torch.optim.Adam([{"params": p} for _, p in ddp16.named_parameters()], lr=1e-3,
                                  weight_decay=1e-5)
         live["ddp"], live["opt"] = ddp16, opt16

@@ -17,6 +17,8 @@ CASES = {
     "allgather": ({"COCLR_SHUFFLE": "allgather"}, "allgather", 0),
     "pull_refused": ({"COCLR_BENCH_FAULT": "pull_map"}, "routed", 0),
     "defer_race": ({"COCLR_BENCH_FAULT": "defer"}, "pull", 1),
+    # BASELINE config 4's model: three encoders, the frozen sampler in eval mode (main_coclr.py:363), mining on
+    "coclr": ({"_ARGS": "--model coclr"}, "pull", 0),
 }
 
 
@@ -27,15 +29,21 @@ def test_bench_n2_rehearsal_on_one_gpu(case):
                      joins deferred in the checked step; fast step == serial step bit for bit
        allgather     the reference's own exchange, forced
        pull_refused  rank 1 cannot export its staging buffers: both ranks agree and stay on the routed exchange
+       coclr         CoCLR two-stream with mining: 2108 tensors (three encoders, four queues, Adam state) bit-identical
+                     between the fast and the serial step.  (The first run of this check on CoCLR FAILED -- and was
+                     right: bench.py called .train() on the self-check's second DDP wrapper, which put the frozen
+                     sampler into training mode for every later step.)
        defer_race    a gradient lost while joins are deferred (only reachable with the real streams): replicas
                      still agree, the self-check does not -- the bench ends on rung 1 with a valid line"""
     env_extra, shuffle, rung = CASES[case]
+    env_extra = dict(env_extra)
+    extra_args = env_extra.pop("_ARGS", "").split()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29761 + list(CASES).index(case)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "bench_rehearse_gpu.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "8", "--moco-k", "2048"]
+           "--batch", "8", "--moco-k", "2048"] + extra_args
     env = dict(os.environ, COCLR_QUIET="1", **env_extra)
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-4000:]
