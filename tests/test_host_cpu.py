@@ -519,6 +519,17 @@ def test_bench_launch_contract_dry_run(world):
         assert mg["rung"] == 0 and len(sc["trials"]) == 1
 
 
+def test_bench_dry_run_coclr_self_check():
+    """BASELINE config 4's model through bench.py at N = 2: the self-check covers three encoders, four queues
+    and the frozen sampler's EVAL mode (main_coclr.py:363) -- a bench that flips it (as `.train()` on the
+    check's second DDP wrapper once did) makes every later step differ from the checked one."""
+    rec, _ = _bench_dry_run(2, 29729, None, ("--model", "coclr"))
+    sc, mg = rec["self_check"], rec["multi_gpu"]
+    assert "CoCLR" in rec["metric"] and rec["value"] > 0
+    assert sc["passed"] is True and sc["rung"] == 0 and mg["rung"] == 0, sc["trials"]
+    assert sc["tensors_compared"] > 2000 and len(sc["trials"]) == 1
+
+
 @pytest.mark.parametrize("fault,rung,attempts", [("defer", 1, 1), ("graphs", 5, 1), ("routed_raises", 4, 2),
                                                  ("routed_hangs", 4, 2)])
 def test_bench_degradation_ladder(fault, rung, attempts):
