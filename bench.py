@@ -198,6 +198,11 @@ class Watchdog:
                     "phase": self.phase[0], "last_collective": self.parallel.LAST[0],
                     "collectives_issued": self.parallel.LAST[2]}
             print("bench watchdog: " + json.dumps(diag), file=sys.stderr, flush=True)
+            try:
+                import faulthandler
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)      # WHERE every thread is stuck
+            except Exception:
+                pass
             bench_multi.write_status(**diag)
             if self.optional and self.record_complete:
                 if self.rank == 0 and self.complete_record is not None:
@@ -407,6 +412,10 @@ _DOG = [None]
 
 
 def measure(args, world):
+    if os.environ.get("COCLR_BENCH_TRACE"):
+        # diagnosis: every N seconds, where is the host?  (stack of every thread to stderr)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["COCLR_BENCH_TRACE"]), repeat=True, file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dry = args.dry_run_host
