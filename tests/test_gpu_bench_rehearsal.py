@@ -17,6 +17,7 @@ CASES = {
     "allgather": ({"COCLR_SHUFFLE": "allgather"}, "allgather", 0),
     "pull_refused": ({"COCLR_BENCH_FAULT": "pull_map"}, "routed", 0),
     "defer_race": ({"COCLR_BENCH_FAULT": "defer"}, "pull", 1),
+    "graph_fault": ({"COCLR_BENCH_FAULT": "graphs"}, "allgather", 5),
     # BASELINE config 4's model: three encoders, the frozen sampler in eval mode (main_coclr.py:363), mining on
     "coclr": ({"_ARGS": "--model coclr"}, "pull", 0),
 }
@@ -33,6 +34,9 @@ def test_bench_n2_rehearsal_on_one_gpu(case):
                      between the fast and the serial step.  (The first run of this check on CoCLR FAILED -- and was
                      right: bench.py called .train() on the self-check's second DDP wrapper, which put the frozen
                      sampler into training mode for every later step.)
+       graph_fault   keys off by 1e-3 whenever the key encoder is replayed from its hipGraph: five rungs differ from
+                     the serial step, the sixth (graphs off; by then also: no deferral, no hook, all-gather exchange)
+                     matches and is the one timed
        defer_race    a gradient lost while joins are deferred (only reachable with the real streams): replicas
                      still agree, the self-check does not -- the bench ends on rung 1 with a valid line"""
     env_extra, shuffle, rung = CASES[case]
@@ -61,6 +65,8 @@ def test_bench_n2_rehearsal_on_one_gpu(case):
     assert [t["bit_identical_to_serial_on_every_rank"] for t in sc["trials"]] == [False] * rung + [True]
     # the checked step is a steady-state one: stages 2-5 left the weight-gradient stream un-joined
     assert sc["deferred_nodes_in_checked_step"] >= 4, sc
+    if rung >= 2:
+        return          # DDP's own all-reduce does not pass the named choke point; exchange checked via shuffle_mode
     if rung == 0:
         assert rec["deferred_joins_per_step"] >= 4
     names = " | ".join(c["collective"] for c in mg["collectives"])
