@@ -168,6 +168,7 @@ class Watchdog:
         self.parallel = parallel
         self.phase = ["start", 0]
         self.done = False
+        self.parent = os.getppid()        # the supervisor (bench_multi.supervise): this process dies with it
         # set once the timed region has been measured: a hang in an OPTIONAL leg after it (host floor at
         # world > 1) must not cost the record -- the watchdog prints it and ends the job successfully
         self.complete_record = None       # rank 0: the record itself
@@ -185,6 +186,8 @@ class Watchdog:
         seen, since = None, time.monotonic()
         while not self.done:
             time.sleep(min(1.0, self.limit / 4))
+            if os.environ.get("COCLR_BENCH_CHILD") == "1" and os.getppid() != self.parent:
+                os._exit(9)               # orphaned: a killed launcher must not leave a rank on a GPU
             cur = (self.phase[1], self.parallel.LAST[2])
             # what the supervisor reads if this process dies without a word (bench_multi.supervise)
             bench_multi.write_status(phase=self.phase[0], last_collective=self.parallel.LAST[0],

@@ -411,7 +411,7 @@ def supervise(argv, hang_timeout, store=None):
         env = dict(os.environ, COCLR_BENCH_CHILD="1", COCLR_BENCH_DIR=adir,
                    COCLR_BENCH_INIT="file://" + os.path.join(adir, "rendezvous"), **rung_env(rung))
         child = subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + argv, env=env,
-                                 stdout=subprocess.PIPE, stderr=None, text=True, preexec_fn=_child_preexec)
+                                 stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
         _CHILDREN.append(child)
         # the child's own watchdog ends a hang after `hang_timeout` without progress; this limit is the
         # backstop for a child that cannot even do that
@@ -514,18 +514,6 @@ def supervise(argv, hang_timeout, store=None):
 _CHILDREN = []
 
 
-def _child_preexec():
-    """The measuring process gets its own process group (so that exactly it and what it starts can be ended)
-    and dies with its supervisor: a launcher that is killed (driver timeout) must not leave a rank on a GPU."""
-    os.setsid()
-    try:
-        import ctypes
-        import signal
-        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)   # PR_SET_PDEATHSIG
-    except Exception:
-        pass
-
-
 def _on_term(signum, frame):
     for c in _CHILDREN:
         if c.poll() is None:
@@ -534,7 +522,11 @@ def _on_term(signum, frame):
 
 
 def _kill(child):
-    """End exactly the process group this supervisor started (os.setsid in _child_preexec)."""
+    """End exactly the process group this supervisor started (start_new_session: the child leads its own
+    session, so exactly it and what it started can be ended).  The other direction -- a supervisor that is
+    killed must not leave a rank on a GPU -- is the child's job: its watchdog thread ends the process when its
+    parent changes (bench.Watchdog), and SIGTERM to a supervisor is forwarded (_on_term).  (No preexec_fn:
+    running Python between fork and exec in a process that has torch's threads can deadlock.)"""
     import signal
     try:
         os.killpg(child.pid, signal.SIGKILL)
