@@ -112,7 +112,8 @@ def test_conditioned_fixture_every_gradient_tensor_decision_conditioned():
         print("   %s: %d in max-pools, %d in ReLUs; largest: %s" % (
             who, pools, sum(f[1] for f in fl) - pools, sorted(fl, key=lambda f: -f[1])[:4]))
     # product vs truth-on-its-decisions, beside oracle fp32 vs truth-on-ITS-decisions
-    table = {k: (l2_table(got, got, t_prod)[k][0], l2_table(g32, g32, t_own)[k][0]) for k in got}
+    tp_, to_ = l2_table(got, got, t_prod), l2_table(g32, g32, t_own)     # (each ONCE: 235 float64 norms apiece)
+    table = {k: (tp_[k][0], to_[k][0]) for k in got}
     _hold(table, "conditioned fixture")
     # the flips themselves are a property of the forward round-off: the product may not make
     # systematically more of them than the reference's arithmetic does
