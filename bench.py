@@ -925,6 +925,8 @@ def measure(args, world):
     if world > 1 and args.model == "infonce" and B >= 16 and K % (4 * world) == 0:
         dog.complete_record, dog.record_complete = rec, True
         dog.at("host floor (4 clips per GPU) -- optional leg", optional=True)
+        if bench_multi.FLOOR_HANG:
+            time.sleep(3600)             # tests: a rank lost in the optional leg
         try:
             floor = small_batch_floor()
             if rank == 0:

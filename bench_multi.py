@@ -56,6 +56,7 @@ RUNG_WHAT = {
     5: "+ hipGraph replay of the key encoder off",
     6: "+ side streams off (every kernel on one stream)",
 }
+FLOOR_HANG = False       # fault injection (tests): see inject_fault("floor_hangs")
 EXIT_MISMATCH = 7        # the self-check failed on the last rung as well
 EXIT_WATCHDOG = 5
 
@@ -327,6 +328,10 @@ def inject_fault(kind, rank):
             raise RuntimeError("hipIpcGetMemHandle: invalid argument (injected)")
         if rank == 1:
             red.reduce_tensor = refuse
+    elif kind == "floor_hangs":
+        # one rank never comes back from the OPTIONAL host-floor leg that follows the timed region
+        global FLOOR_HANG
+        FLOOR_HANG = rank == 1
     elif kind == "dies":
         # a rank that disappears in its first exchange on the fast rungs (stands for a GPU memory fault)
         native = dist.all_to_all_single

@@ -26,5 +26,8 @@ if __name__ == "__main__":
     torch.set_num_threads(1)
     fake_backend.install(_MP)
     import bench
-    sys.argv += ["--dry-run-host", "--seq-len", "8", "--img-dim", "32", "--batch", "2"]
+    sys.argv += ["--dry-run-host"]
+    for flag, val in (("--seq-len", "8"), ("--img-dim", "32"), ("--batch", "2")):
+        if flag not in sys.argv:
+            sys.argv += [flag, val]
     bench.main()

@@ -474,19 +474,27 @@ def _bench_dry_run(world, port, extra_env=None, extra_args=()):
 @pytest.mark.parametrize("world", [1, 2, 8])
 def test_bench_launch_contract_dry_run(world):
     """One JSON line from rank 0 with the contract's fields, whole-job value = B*world*steps/time, K = 16384
-    and weak scaling at world > 1.  At world 8 a fault is injected into the bucket hook (a bucket all-reduced
-    with a wrong gradient in it -- identical on every rank, so replicas still agree): the self-check must
-    see it and the bench must end, with a valid value, on the rung that switches the hook off."""
-    fault = {"COCLR_BENCH_FAULT": "hook"} if world == 8 else None
-    rec, _ = _bench_dry_run(world, 29720 + world, fault)
+    and weak scaling at world > 1.
+    World 8: a fault is injected into the bucket hook (a bucket all-reduced with a wrong gradient in it --
+    identical on every rank, so replicas still agree): the self-check must see it and the bench must end, with a
+    valid value, on the rung that switches the hook off.
+    World 2 (16 clips per rank, so that the OPTIONAL host-floor leg after the timed region runs): rank 1 never comes
+    back from that leg -- the watchdog must print the record that is already complete, flagged
+    `optional_leg_hung`, and every process must exit 0: a hang after the measurement cannot cost the measurement."""
+    fault = {"COCLR_BENCH_FAULT": "hook"} if world == 8 else \
+        ({"COCLR_BENCH_FAULT": "floor_hangs"} if world == 2 else None)
+    extra = ("--batch", "16", "--moco-k", "64", "--hang-timeout", "6") if world == 2 else ()
+    rec, _ = _bench_dry_run(world, 29720 + world, fault, extra)
+    B = 16 if world == 2 else 2
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in rec, key
     assert rec["n_gpus"] == world and rec["steps"] == 2 and rec["warmup"] == 1
     assert rec["scaling"] == "weak" and rec["higher_is_better"] is True and rec["dtype"] == "fp32"
-    assert rec["config"]["global_batch"] == 2 * world and "DRY RUN" in rec["data"]
-    assert ("moco-k=16384" in rec["config"]["workload"]) == (world > 1)
-    assert abs(rec["value"] - 2 * world * 2 / (rec["ms_per_step"] * 2e-3)) <= 0.02 * rec["value"]
+    assert rec["config"]["global_batch"] == B * world and "DRY RUN" in rec["data"]
+    assert ("moco-k=16384" in rec["config"]["workload"]) == (world == 8)
+    assert ("moco-k=64 " in rec["config"]["workload"]) == (world == 2)
+    assert abs(rec["value"] - B * world * 2 / (rec["ms_per_step"] * 2e-3)) <= 0.02 * rec["value"]
     # the fast-vs-serial bit-identity check of one step runs at every world size
     sc = rec["self_check"]
     assert sc["passed"] is True and sc["tensors_compared"] > 1000
@@ -517,6 +525,8 @@ def test_bench_launch_contract_dry_run(world):
         assert mg["cross_rank"]["replicas_identical"] is True      # ... which replicas-identical cannot see
     else:
         assert mg["rung"] == 0 and len(sc["trials"]) == 1
+        hung = rec["optional_leg_hung"]
+        assert "host floor" in hung["phase"] and "host_floor_ms_per_step" not in mg
 
 
 def test_bench_dry_run_coclr_self_check():
