@@ -420,7 +420,7 @@ def supervise(argv, hang_timeout, store=None):
         _CHILDREN.append(child)
         # the child's own watchdog ends a hang after `hang_timeout` without progress; this limit is the
         # backstop for a child that cannot even do that
-        limit = time.monotonic() + float(os.environ.get("COCLR_BENCH_ATTEMPT_LIMIT", 8 * hang_timeout + 900))
+        limit = time.monotonic() + float(os.environ.get("COCLR_BENCH_ATTEMPT_LIMIT", 4 * hang_timeout + 600))
         out, peer_failed_at, killed = None, None, False
         keys = [pre + "%d/status/%d" % (attempt, r) for r in range(world)]
         while True:
@@ -462,7 +462,7 @@ def supervise(argv, hang_timeout, store=None):
         store.set(keys[rank], json.dumps(status))
         # every supervisor reports within the attempt limit (a child cannot outlive it); peers that do not are
         # counted as failed rather than waited for forever
-        _wait_keys(store, keys, float(os.environ.get("COCLR_BENCH_ATTEMPT_LIMIT", 8 * hang_timeout + 900)) + 60)
+        _wait_keys(store, keys, float(os.environ.get("COCLR_BENCH_ATTEMPT_LIMIT", 4 * hang_timeout + 600)) + 60)
         statuses = [json.loads(store.get(k).decode()) if store.check([k]) else
                     {"rank": r, "rc": -1, "error": "its supervisor did not report"} for r, k in enumerate(keys)]
         ok = all(s["rc"] == 0 for s in statuses)
