@@ -18,6 +18,10 @@ if __name__ == "__main__":
     import torch
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # Two PROCESSES share this GPU: with each one's weight-gradient stream at high priority (the product's default)
+    # rank A's weight gradients starve rank B's data-gradient chain and vice versa -- steps of a second instead of
+    # 40 ms.  One process per GPU never meets that; the rehearsal runs the streams at equal priority.
+    os.environ.setdefault("COCLR_WGRAD_PRIORITY", "0")
     gather_native, a2a_native = dist.all_gather_into_tensor, dist.all_to_all_single
 
     def all_gather_into_tensor(out, tensor, *a, **kw):

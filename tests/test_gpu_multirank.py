@@ -21,6 +21,8 @@ def _worker(rank, world, kind, port, q):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # two processes on ONE GPU: equal stream priorities (see tests/bench_rehearse_gpu.py)
+        os.environ.setdefault("COCLR_WGRAD_PRIORITY", "0")
         import sys
         here = os.path.dirname(os.path.abspath(__file__))
         for p in (here, os.path.dirname(here)):
