@@ -208,7 +208,7 @@ class Watchdog:
                 pass
             bench_multi.write_status(**diag)
             if self.optional and self.record_complete:
-                if self.rank == 0 and self.complete_record is not None:
+                if self.rank == 0 and self.complete_record is not None and not getattr(self, "printed", False):
                     rec = dict(self.complete_record, optional_leg_hung=diag)
                     print(json.dumps(rec), flush=True)
                 os._exit(0)
@@ -937,16 +937,28 @@ def measure(args, world):
     if dog is not None:
         dog.at("final barrier", optional=True)
     dist.barrier()
+
+    def emit():
+        if rank == 0:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)      # RCCL's banner sits in the C stdio buffer
+            sys.stdout.flush()
+            print(json.dumps(rec), flush=True)
+
     if dog is not None:
+        # world > 1 (a supervised child): the line goes out BEFORE the process group is torn down -- a
+        # destroy_process_group() that never returns must not cost a finished measurement (the supervisor takes
+        # the last JSON line whatever follows it on stdout; the watchdog ends a stuck teardown with exit code 0)
+        emit()
+        dog.complete_record, dog.record_complete, dog.printed = None, True, True
+        dog.at("destroy_process_group", optional=True)
+        bench_multi.write_status(phase="done")
+        dist.destroy_process_group()
         dog.done = True
+        return
     bench_multi.write_status(phase="done")
     dist.destroy_process_group()
-    if rank == 0:
-        # last thing on stdout (RCCL prints its banner lazily during the run)
-        import ctypes
-        ctypes.CDLL(None).fflush(None)      # RCCL's banner sits in the C stdio buffer
-        sys.stdout.flush()
-        print(json.dumps(rec), flush=True)
+    emit()          # world 1: last thing on stdout (RCCL prints its banner lazily during the run)
 
 
 if __name__ == "__main__":
