@@ -401,6 +401,7 @@ def supervise(argv, hang_timeout, store=None):
     pre = "coclr_bench/%s/" % os.environ.get("TORCHELASTIC_RUN_ID", "run")
     rung = int(os.environ.get("COCLR_BENCH_RUNG", "0"))
     attempts = []
+    attempt_dirs = []
     final_line = None
     succeeded = False
     max_attempts = int(os.environ.get("COCLR_BENCH_ATTEMPTS", "3"))
@@ -408,6 +409,7 @@ def supervise(argv, hang_timeout, store=None):
         # ---- a directory for this attempt (rendezvous file of the children, their status files) -------
         if rank == 0:
             adir = tempfile.mkdtemp(prefix="coclr_bench_a%d_" % attempt)
+            attempt_dirs.append(adir)
             store.set(pre + "%d/dir" % attempt, adir)
         else:
             if not _wait_keys(store, [pre + "%d/dir" % attempt], 1800):
@@ -513,6 +515,9 @@ def supervise(argv, hang_timeout, store=None):
     store.set(pre + "done/%d" % rank, "1")
     if rank == 0:
         _wait_keys(store, [pre + "done/%d" % r for r in range(world)], 120)
+        import shutil
+        for d in attempt_dirs:               # rendezvous files and status files of the attempts
+            shutil.rmtree(d, ignore_errors=True)
     return 0 if succeeded else 1
 
 
