@@ -33,7 +33,8 @@ Rungs (cumulative):
     3 -pull     shuffle-BN exchange = RCCL all_to_all_single (COCLR_SHUFFLE=routed)
     4 -routed   shuffle-BN exchange = the reference's all-gather (COCLR_SHUFFLE=allgather)
     5 -graphs   key encoder launched eagerly (COCLR_GRAPHS=0)
-    6 serial    one stream: no key-encoder stream, no weight-gradient stream
+    6 serial    one stream: no key-encoder stream, no weight-gradient stream; the queues re-sent from rank 0 with
+                every forward, as DDP(broadcast_buffers=True) does
 """
 import json
 import os
@@ -54,7 +55,7 @@ RUNG_WHAT = {
     3: "+ peer row pull off (routed all_to_all_single)",
     4: "+ routed exchange off (the reference's all-gather)",
     5: "+ hipGraph replay of the key encoder off",
-    6: "+ side streams off (every kernel on one stream)",
+    6: "+ side streams off (every kernel on one stream), queues in every buffer broadcast",
 }
 FLOOR_HANG = False       # fault injection (tests): see inject_fault("floor_hangs")
 EXIT_MISMATCH = 7        # the self-check failed on the last rung as well
@@ -75,6 +76,7 @@ class Switches:
         self.engine, self.impl = engine, impl
         self.base = {"defer": engine.DEFER_JOIN, "shuffle": impl._SHUFFLE_MODE, "graphs": impl._GRAPHS,
                      "wgrad_stream": engine.WGRAD_STREAM, "overlap_keys": impl._OVERLAP_KEYS,
+                     "sync_queues": impl._SYNC_QUEUES,
                      "hook": os.environ.get("COCLR_DDP_HOOK", "1") != "0"
                      and os.environ.get("COCLR_PATCH_DDP", "1") != "0"}
         self.rung = 0
@@ -97,12 +99,14 @@ class Switches:
         m._GRAPHS = b["graphs"] and rung < 5
         e.WGRAD_STREAM = b["wgrad_stream"] and rung < 6
         m._OVERLAP_KEYS = b["overlap_keys"] and rung < 6
+        m._SYNC_QUEUES = b["sync_queues"] or rung >= 6      # serial: queues re-sent with every forward (the reference)
         self.rung = rung
 
     def describe(self):
         e, m = self.engine, self.impl
         return {"defer_join": bool(e.DEFER_JOIN), "shuffle": m._SHUFFLE_MODE, "graphs": bool(m._GRAPHS),
-                "wgrad_stream": bool(e.WGRAD_STREAM), "key_stream": bool(m._OVERLAP_KEYS)}
+                "wgrad_stream": bool(e.WGRAD_STREAM), "key_stream": bool(m._OVERLAP_KEYS),
+                "queues_in_every_broadcast": bool(m._SYNC_QUEUES)}
 
 
 def rung_env(rung):

@@ -40,6 +40,13 @@ _CHUNK = 32768   # elements per workgroup of the momentum kernel
 #               its place on the data path at run time instead of behind an environment variable
 _SHUFFLE_MODE = os.environ.get("COCLR_SHUFFLE", "auto")
 _SHUFFLE_INFO = {"requested": _SHUFFLE_MODE}       # how the mode in force was arrived at (bench.py prints it)
+# DDP(broadcast_buffers=True) re-sends rank 0's QUEUES with every forward (main_nce.py:172).  They are the
+# one part of the buffers that cannot differ between ranks once they have been made equal: every rank enqueues
+# the same gathered keys at the same pointer (ref :82-96).  So they travel with the FIRST broadcast after
+# construction / load_state_dict / a storage move -- when ranks may hold different random queues -- and not
+# again: 0.5 MB of BatchNorm statistics per forward instead of 8.9 MB at K = 16384 (17 MB for CoCLR).
+# COCLR_SYNC_QUEUES=1 re-sends them with every forward, as the reference does.
+_SYNC_QUEUES = os.environ.get("COCLR_SYNC_QUEUES", "0") != "0"
 _OVERLAP_KEYS = os.environ.get("COCLR_OVERLAP_KEYS", "1") != "0"
 _GRAPHS = os.environ.get("COCLR_GRAPHS", "1") != "0"
 
@@ -428,6 +435,7 @@ class InfoNCE(nn.Module):
     def _load_from_state_dict(self, *args, **kwargs):
         # a resumed queue_ptr must be re-validated against the batch it will be used with
         self.__dict__["_ptr_checked_for"] = None
+        self.__dict__["_sync_full_next"] = True     # loaded queues may differ between ranks until broadcast
         return super()._load_from_state_dict(*args, **kwargs)
 
     def _check_queue_ptr(self, batch_size):
@@ -458,20 +466,24 @@ class InfoNCE(nn.Module):
         """One allocation PER DTYPE (fp32: BN statistics and the queues; int64: counters, pointer,
         name / label queues).  Not one for everything: torch.save refuses tensors of different dtypes
         that view one storage, and the launch scripts checkpoint `state_dict()` as it is
-        (main_nce.py:278-290)."""
+        (main_nce.py:278-290).  The model's own queue buffers sit at the END of their allocation, so that
+        the steady-state broadcast (see _SYNC_QUEUES) is a prefix."""
         seen, entries = set(), []
         for mod in self.modules():
             for key, b in mod._buffers.items():
                 if b is not None and id(b) not in seen:
                     seen.add(id(b))
                     entries.append((mod, key, b))
-        flats = []
+        flats, steady = [], []
         for dtype in sorted({b.dtype for _, _, b in entries}, key=str):
             mine = [(mod, key, b) for mod, key, b in entries if b.dtype == dtype]
+            mine.sort(key=lambda e: e[0] is self and e[1].startswith("queue"))      # stable: queues last
             esz = mine[0][2].element_size()
             pad = max(1, 16 // esz)
-            offs, total = [], 0
-            for _, _, b in mine:
+            offs, total, prefix = [], 0, None
+            for mod, key, b in mine:
+                if prefix is None and mod is self and key.startswith("queue"):
+                    prefix = total
                 offs.append(total)
                 total += (b.numel() + pad - 1) // pad * pad
             flat = torch.empty(total, dtype=dtype, device=self.queue.device)
@@ -481,7 +493,11 @@ class InfoNCE(nn.Module):
                     v.copy_(b)
                     mod._buffers[key] = v
             flats.append(flat)
+            # only the big floating-point allocation is worth a second message size
+            steady.append(total if (prefix is None or not dtype.is_floating_point) else prefix)
         self.__dict__["_flat_buffers"] = flats
+        self.__dict__["_flat_steady"] = steady
+        self.__dict__["_sync_full_next"] = True
 
     def _sync_buffers(self):
         dev = self.queue.device
@@ -502,12 +518,18 @@ class InfoNCE(nn.Module):
             # new_group is a collective: every rank creates the host-side channel HERE, at its first
             # forward, whatever shuffle scheme / train-or-eval path it takes afterwards
             self._host_group()
+            full = _SYNC_QUEUES or self.__dict__.get("_sync_full_next", True)
+            self.__dict__["_sync_full_next"] = False
             with torch.no_grad():
-                for flat in flats:
-                    _coll("broadcast of the flat %s buffer allocation (pretrain._sync_buffers; DDP "
-                          "broadcast_buffers, main_nce.py:172)" % str(flat.dtype).replace("torch.", ""),
-                          lambda flat=flat: dist.broadcast(flat, src=0),
-                          flat.numel() * flat.element_size(), flat.device)
+                for flat, n in zip(flats, self.__dict__["_flat_steady"]):
+                    part = flat if (full or n >= flat.numel()) else flat[:n]
+                    if part.numel() == 0:
+                        continue
+                    _coll("broadcast of the flat %s buffer allocation%s (pretrain._sync_buffers; DDP "
+                          "broadcast_buffers, main_nce.py:172)"
+                          % (str(flat.dtype).replace("torch.", ""), "" if part is flat else " without the queues"),
+                          lambda part=part: dist.broadcast(part, src=0),
+                          part.numel() * part.element_size(), flat.device)
 
     # -- momentum encoder ---------------------------------------------------------
     def _build_momentum_table(self):

@@ -452,6 +452,102 @@ def test_four_and_eight_rank_gloo(world, kind, port):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
+def _queue_sync_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        class MP:
+            @staticmethod
+            def setattr(obj, name, val):
+                setattr(obj, name, val)
+        fake_backend.install(MP)
+        import coclr_amd.model.pretrain as impl
+        import model.pretrain as product
+        from coclr_amd import parallel
+        B, K, clip = 2, 64, (3, 8, 32, 32)
+
+        def run(sync_queues):
+            impl._SYNC_QUEUES = sync_queues
+            torch.manual_seed(0)
+            model = product.CoCLR('s3d', 128, K, 0.999, 0.07, topk=5)
+            # every rank starts from ITS OWN random queues (an unseeded launch script) ...
+            g = torch.Generator().manual_seed(100 + rank)
+            model.queue.copy_(torch.nn.functional.normalize(torch.randn(128, K, generator=g), dim=0))
+            model.queue_second.copy_(torch.nn.functional.normalize(torch.randn(128, K, generator=g), dim=0))
+            model.queue_label.fill_(1)
+            model.queue_vname.copy_(torch.randint(0, 6, (K,), generator=torch.Generator().manual_seed(7)))
+            ddp = torch.nn.parallel.DistributedDataParallel(model)
+            opt = torch.optim.Adam([{"params": p} for _, p in ddp.named_parameters()], lr=1e-3, weight_decay=1e-5)
+            ddp.train()
+            model.sampler.eval()
+            sizes, outs = [], []
+            for step in range(3):
+                g = torch.Generator().manual_seed(50 + step)
+                blocks = [torch.randn(B * world, 2, *clip, generator=g) for _ in range(2)]
+                vsrc = torch.randint(0, 6, (B * world,), generator=g)
+                sl = slice(rank * B, (rank + 1) * B)
+                torch.manual_seed(900 + step)
+                parallel.TIMINGS = []
+                out, mask = ddp(blocks[0][sl], blocks[1][sl], vsrc[sl])
+                rows, parallel.TIMINGS = parallel.TIMINGS, None
+                sizes.append(sum(nb for name, nb, _ in rows if "flat float32 buffer" in name))
+                loss = (- torch.log((torch.softmax(out, dim=1) * mask).sum(1))).mean()
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                outs.append(out.detach().clone())
+                if step == 1:
+                    # ... and a state dict loaded mid-run (resume) makes the next forward send everything again
+                    model.load_state_dict(model.state_dict())
+            return sizes, outs, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+        sizes, outs, sd = run(False)
+        sizes_ref, outs_ref, sd_ref = run(True)
+        qbytes = 2 * 128 * K * 4
+        assert sizes_ref[0] == sizes_ref[1] == sizes_ref[2] and sizes_ref[0] > qbytes, sizes_ref
+        # first forward: everything (the ranks' queues differ); second: the BatchNorm statistics only; third:
+        # everything again (load_state_dict in between)
+        assert sizes[0] == sizes_ref[0] and sizes[2] == sizes_ref[0], (sizes, sizes_ref)
+        assert sizes[1] == sizes_ref[0] - qbytes, (sizes, sizes_ref)
+        # same results as re-sending the queues with every forward (the reference's DDP broadcast_buffers)
+        for a, b in zip(outs, outs_ref):
+            assert torch.equal(a, b)
+        for k in sd:
+            assert torch.equal(sd[k], sd_ref[k]), k
+        # rank 0's queues won on every rank (BatchNorm statistics are rank-local until the next forward's broadcast)
+        for k in ("queue", "queue_second", "queue_ptr", "queue_vname"):
+            t = sd[k].double().reshape(-1)
+            digest = torch.stack([t.sum(), (t * torch.arange(1, t.numel() + 1, dtype=torch.float64)).sum()])
+            got = [torch.zeros_like(digest) for _ in range(world)]
+            dist.all_gather(got, digest)
+            assert all(torch.equal(got[0], d) for d in got), "replicas diverged in " + k
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+def test_queues_travel_with_the_first_broadcast_only():
+    """DDP(broadcast_buffers=True) re-sends the queues from rank 0 with every forward (main_nce.py:172).  Here
+    they travel with the first broadcast after construction / load_state_dict -- when ranks may hold different
+    random queues -- and not again (every rank enqueues the same gathered keys at the same pointer): the
+    steady-state broadcast is the BatchNorm statistics.  Results identical to re-sending them every time."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_queue_sync_worker, args=(r, 2, 29745, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
 def _bench_dry_run(world, port, extra_env=None, extra_args=()):
     """bench.py exactly as the driver launches it (torch.distributed.run, one process per rank) on the host
     with the ATen double; returns (the ONE JSON line rank 0 printed, stderr)."""
