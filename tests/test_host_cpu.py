@@ -636,14 +636,14 @@ def test_bench_dry_run_coclr_self_check():
     assert sc["tensors_compared"] > 2000 and len(sc["trials"]) == 1
 
 
-@pytest.mark.parametrize("fault,rung,attempts", [("defer", 1, 1), ("routed_raises", 4, 2), ("routed_hangs", 4, 2)])
+@pytest.mark.parametrize("fault,rung,attempts", [("routed_raises", 4, 2), ("routed_hangs", 4, 2)])
 def test_bench_degradation_ladder(fault, rung, attempts):
     """a fault at each kind of rung, and bench.py still finishes with ONE valid line
     whose `multi_gpu.rung` names what had to be switched off.
-      defer            a wrong result tied to the switch (a lost gradient while joins are deferred): found by
-                       the self-check, walked down IN PROCESS to the first rung that is bit-identical to the
-                       serial step (the bucket-hook fault rides on the W = 8 dry run above; keys off by 1e-3
-                       under graph replay -- rung 5 -- on the one-GPU rehearsal, tests/test_gpu_bench_rehearsal.py)
+      (wrong RESULTS tied to a switch are found by the self-check and walked down IN PROCESS: the bucket-hook
+       fault rides on the W = 8 dry run above -- rung 2; a gradient lost while joins are deferred -- rung 1 --
+       and keys off by 1e-3 under graph replay -- rung 5 -- on the one-GPU rehearsal with the real streams,
+       tests/test_gpu_bench_rehearsal.py)
       routed_raises    the backend refuses all_to_all_single on every rank: the attempt ends, the supervisors
                        read WHICH exchange failed and start a new set of processes on the all-gather rung
       routed_hangs     one rank never enters the exchange: the watchdog names it after --hang-timeout and
