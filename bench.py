@@ -372,12 +372,37 @@ def dominant_kernel_name(algo):
     return "conv_wino_hw_kernel<8,6|10> Winograd F(2x2,3x3), 4-byte window DMA"
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: run the command the driver would have typed --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    <this script> <same arguments>` -- as a child, with its stdout / stderr passed through (rank 0's ONE JSON
+    line included), and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    print("bench: no launcher around --gpus %d, starting the ranks: %s" % (n, " ".join(cmd)), file=sys.stderr,
+          flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL / hipIpc across processes need it here
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves, one per GPU, through the same launcher
+        # the driver uses (this process only waits for it and hands its exit code on)
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run "
+                         "--nproc-per-node %d, or unset WORLD_SIZE and let bench.py start the ranks)"
+                         % (args.gpus, world, args.gpus))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
     if world > 1 and os.environ.get("COCLR_BENCH_CHILD") != "1" and \

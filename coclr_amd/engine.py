@@ -101,8 +101,8 @@ def _end_of_backward(device):
     LAST deferred as well (stage 1 frozen or not part of the graph), nobody has joined the weight-gradient
     stream -- do it here, in front of the optimiser, and release what its kernels read."""
     _CALLBACK_QUEUED[device] = False
-    pending = _PENDING_SIDE.pop(device, None)
-    if pending and device in _SIDE:
+    _PENDING_SIDE.pop(device, None)
+    if device in _SIDE:        # unconditional: a join of a drained stream costs one event, a missing one a race
         torch.cuda.current_stream(device).wait_stream(_SIDE[device])
 
 
@@ -141,14 +141,29 @@ def set_grad_slot(param, view):
             del _GRAD_SLOTS[k_]
 
 
+_HEAD_SLOTS_OUT = set()   # parameters whose bucket view grad_out_for has handed out since the last forward
+
+
+def new_pass(device):
+    """Start of a differentiated forward: state that belongs to ONE forward/backward pair is reset here, because
+    autograd runs no end-of-pass callback when a backward pass raises (OOM, a collective error): the
+    end-of-backward join would otherwise never be queued again, and a bucket view handed out by a pass that died
+    would stay 'taken'."""
+    _CALLBACK_QUEUED[device] = False
+    _HEAD_SLOTS_OUT.clear()
+
+
 def grad_out_for(p):
     """Run.grad_out for code outside an engine run (the projection head, coclr_amd/model/pretrain.py): a
     fresh alias of p's DistributedDataParallel bucket view when there is one and `.grad` is unset -- the
-    kernel then writes the gradient where DDP wants it and DDP copies nothing -- else new memory."""
+    kernel then writes the gradient where DDP wants it and DDP copies nothing -- else new memory.  Once per
+    parameter and pass: a second node over the same weights (the model run twice, one backward over both
+    graphs) gets its own memory and autograd adds the two."""
     slot = _GRAD_SLOTS.get(id(p)) if _GRAD_SLOTS else None
-    if slot is not None and slot[0]() is p and p.grad is None:
+    if slot is not None and slot[0]() is p and p.grad is None and id(p) not in _HEAD_SLOTS_OUT:
         v = slot[1]
         if v.device == p.device and v.shape == p.shape and v.dtype == p.dtype:
+            _HEAD_SLOTS_OUT.add(id(p))
             return v.view_as(v)
     return torch.empty_like(p)
 
@@ -1194,6 +1209,7 @@ class EngineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, kwargs, x, *params):
         need_dx = x.requires_grad
+        new_pass(x.device)
         run = Run(x.device, save=True, need_input_grad=need_dx)
         xin = Val(x if _dense5(x) else x.contiguous())
         if not need_dx:
@@ -1368,6 +1384,7 @@ class GraphedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ent, x, *params):
+        new_pass(x.device)
         if ent.static_in is None or x.data_ptr() != ent.x.data_ptr():
             _copy_rows(x.detach(), ent.x)
         ent.fwd.replay()

@@ -51,6 +51,12 @@ _OVERLAP_KEYS = os.environ.get("COCLR_OVERLAP_KEYS", "1") != "0"
 _GRAPHS = os.environ.get("COCLR_GRAPHS", "1") != "0"
 
 
+def _par_issued():
+    """Collectives this rank has entered so far (coclr_amd.parallel.collective counts them)."""
+    from .. import parallel as _par
+    return _par.LAST[2]
+
+
 def _world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(), dist.get_rank()
@@ -517,8 +523,20 @@ class InfoNCE(nn.Module):
         if world > 1:
             # new_group is a collective: every rank creates the host-side channel HERE, at its first
             # forward, whatever shuffle scheme / train-or-eval path it takes afterwards
-            self._host_group()
-            full = _SYNC_QUEUES or self.__dict__.get("_sync_full_next", True)
+            grp = self._host_group()
+            full = _SYNC_QUEUES
+            if not full:
+                # The message size must be the SAME on every rank, and a rank's own flag is local knowledge:
+                # load_state_dict on rank 0 alone is legal under the reference (DDP re-sends rank 0's buffers with
+                # every forward), so is a re-flatten after `.to()` on some ranks.  The ranks therefore agree on
+                # the host first -- eight bytes over the gloo side channel, MAX over the flags: if ANY rank's
+                # queues may be stale, everybody takes part in the whole-allocation broadcast.  No device sync.
+                # (In-place edits of the queues that bypass load_state_dict must set `_sync_full_next = True`
+                # themselves, or run with COCLR_SYNC_QUEUES=1.)
+                flag = torch.tensor([1 if self.__dict__.get("_sync_full_next", True) else 0])
+                _coll("host agreement on the buffer broadcast size over gloo (pretrain._sync_buffers)",
+                      lambda: dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=grp), 8)
+                full = bool(int(flag[0]))
             self.__dict__["_sync_full_next"] = False
             with torch.no_grad():
                 for flat, n in zip(flats, self.__dict__["_flat_steady"]):
@@ -982,6 +1000,8 @@ class InfoNCE(nn.Module):
         perm = self._host_perm(x2.shape[0] * world)
         routed = self._routed_shuffle(x2, perm=perm)
         same, why = 0, "the pull raised"
+        st = self.__dict__.get("_peer_stage_state")
+        issued = _par_issued()
         try:
             pulled = self._pull_shuffle(x2, perm=perm)
             if pulled is not None:
@@ -990,6 +1010,15 @@ class InfoNCE(nn.Module):
                 why = "the clips pulled differ from the clips routed" if not same else ""
         except Exception as e:            # the verdict below must still be reached by every rank
             why = "the pull raised %s" % (str(e)[:160],)
+            # ... and so must the DEVICE collective sequence stay aligned: the peers enqueued the pull's
+            # one-element all-reduce; if this rank raised in front of it, it posts the matching call now
+            # (otherwise the next all-to-all here would pair with that stale all-reduce over there)
+            if st is not None and _par_issued() == issued:
+                try:
+                    _coll("one-element all_reduce matching the peers' 'everybody has parked' (pretrain._auto_shuffle)",
+                          lambda: dist.all_reduce(st["sync"]), 4, x2.device)
+                except Exception:
+                    pass
         ok = torch.tensor([same], dtype=torch.int32)
         _coll("host all_reduce(MIN) 'pull == routed on every rank' over gloo (pretrain._auto_shuffle)",
               lambda: dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self._host_group()))

@@ -189,12 +189,10 @@ def bucket_hook(state, bucket):
         # ... behind the weight gradients of THIS bucket only: every node records one event on the weight-
         # gradient stream when its last weight gradient has been enqueued (engine.side_events_for); waiting
         # for the whole stream would also wait for later stages' weight gradients that are already queued
-        events = engine.side_events_for(params)
-        if events is None:
-            prep.wait_stream(side)
-        else:
-            for ev in events:
-                prep.wait_event(ev)
+        # (an empty list = no node of this bucket deferred its join: the main stream, which `prep` waited for
+        # above, already orders those gradients)
+        for ev in engine.side_events_for(params):
+            prep.wait_event(ev)
         with torch.cuda.stream(prep):
             buf.div_(world)
             work = collective("ddp bucket %d all_reduce (parallel.bucket_hook; main_nce.py:172)" % idx,

@@ -499,9 +499,14 @@ def _queue_sync_worker(rank, world, port, q):
                 loss.backward()
                 opt.step()
                 outs.append(out.detach().clone())
-                if step == 1:
-                    # ... and a state dict loaded mid-run (resume) makes the next forward send everything again
-                    model.load_state_dict(model.state_dict())
+                if step == 1 and rank == 0:
+                    # ... and a state dict loaded mid-run ON RANK 0 ALONE (legal under the reference: DDP re-sends
+                    # rank 0's buffers with every forward) makes the next forward send everything again ON EVERY
+                    # RANK: the ranks agree on the message size over the host channel first (a rank sizing the
+                    # broadcast from its own flag would post a different count than its peers)
+                    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+                    sd0["queue"] = sd0["queue"].flip(1)
+                    model.load_state_dict(sd0)
             return sizes, outs, {k: v.detach().clone() for k, v in model.state_dict().items()}
 
         sizes, outs, sd = run(False)
@@ -548,18 +553,24 @@ def test_queues_travel_with_the_first_broadcast_only():
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
-def _bench_dry_run(world, port, extra_env=None, extra_args=()):
+def _bench_dry_run(world, port, extra_env=None, extra_args=(), bare=False):
     """bench.py exactly as the driver launches it (torch.distributed.run, one process per rank) on the host
-    with the ATen double; returns (the ONE JSON line rank 0 printed, stderr)."""
+    with the ATen double; returns (the ONE JSON line rank 0 printed, stderr).
+    bare: no launcher -- a plain `python <script> --gpus N`, which has to start the N ranks itself
+    (bench.self_launch)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "tests", "bench_dryrun.py"), "--gpus", str(world), "--steps", "2",
-           "--warmup", "1"] + list(extra_args)
+    launcher = [] if bare else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                                "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd = [sys.executable] + launcher + [
+        os.path.join(root, "tests", "bench_dryrun.py"), "--gpus", str(world), "--steps", "2",
+        "--warmup", "1"] + list(extra_args)
     env = dict(os.environ, OMP_NUM_THREADS="1", COCLR_QUIET="1", **(extra_env or {}))
+    if bare:
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -576,11 +587,14 @@ def test_bench_launch_contract_dry_run(world):
     valid value, on the rung that switches the hook off.
     World 2 (16 clips per rank, so that the OPTIONAL host-floor leg after the timed region runs): rank 1 never comes
     back from that leg -- the watchdog must print the record that is already complete, flagged
-    `optional_leg_hung`, and every process must exit 0: a hang after the measurement cannot cost the measurement."""
+    `optional_leg_hung`, and every process must exit 0: a hang after the measurement cannot cost the measurement.
+    World 2 is also started BARE -- `python <script> --gpus 2`, no torch.distributed.run around it, the way the
+    round-5 driver typed its bench command: bench.py has to start the two ranks itself (bench.self_launch)."""
     fault = {"COCLR_BENCH_FAULT": "hook"} if world == 8 else \
         ({"COCLR_BENCH_FAULT": "floor_hangs"} if world == 2 else None)
     extra = ("--batch", "16", "--moco-k", "64", "--hang-timeout", "6") if world == 2 else ()
-    rec, _ = _bench_dry_run(world, 29720 + world, fault, extra)
+    rec, err = _bench_dry_run(world, 29720 + world, fault, extra, bare=world == 2)
+    assert ("starting the ranks" in err) == (world == 2)
     B = 16 if world == 2 else 2
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
