@@ -32,7 +32,7 @@ Rungs (cumulative):
     2 -hook     DDP's own per-parameter bucket copies, no engine writes into bucket views (COCLR_DDP_HOOK=0)
     3 -pull     shuffle-BN exchange = RCCL all_to_all_single (COCLR_SHUFFLE=routed)
     4 -routed   shuffle-BN exchange = the reference's all-gather (COCLR_SHUFFLE=allgather)
-    5 -graphs   key encoder launched eagerly (COCLR_GRAPHS=0)
+    5 -graphs   key encoder launched eagerly (COCLR_GRAPHS=0), query encoder interpreted (COCLR_PLAN=0)
     6 serial    one stream: no key-encoder stream, no weight-gradient stream; the queues re-sent from rank 0 with
                 every forward, as DDP(broadcast_buffers=True) does
 """
@@ -76,6 +76,7 @@ class Switches:
         self.engine, self.impl = engine, impl
         self.base = {"defer": engine.DEFER_JOIN, "shuffle": impl._SHUFFLE_MODE, "graphs": impl._GRAPHS,
                      "wgrad_stream": engine.WGRAD_STREAM, "overlap_keys": impl._OVERLAP_KEYS,
+                     "plan": engine.PLAN,
                      "sync_queues": impl._SYNC_QUEUES,
                      "hook": os.environ.get("COCLR_DDP_HOOK", "1") != "0"
                      and os.environ.get("COCLR_PATCH_DDP", "1") != "0"}
@@ -97,6 +98,7 @@ class Switches:
             shuffle = "allgather"
         m._SHUFFLE_MODE = shuffle
         m._GRAPHS = b["graphs"] and rung < 5
+        e.PLAN = b["plan"] and rung < 5          # launch-plan replay of the query encoder goes with the graphs
         e.WGRAD_STREAM = b["wgrad_stream"] and rung < 6
         m._OVERLAP_KEYS = b["overlap_keys"] and rung < 6
         m._SYNC_QUEUES = b["sync_queues"] or rung >= 6      # serial: queues re-sent with every forward (the reference)
@@ -105,7 +107,7 @@ class Switches:
     def describe(self):
         e, m = self.engine, self.impl
         return {"defer_join": bool(e.DEFER_JOIN), "shuffle": m._SHUFFLE_MODE, "graphs": bool(m._GRAPHS),
-                "wgrad_stream": bool(e.WGRAD_STREAM), "key_stream": bool(m._OVERLAP_KEYS),
+                "launch_plans": bool(e.PLAN), "wgrad_stream": bool(e.WGRAD_STREAM), "key_stream": bool(m._OVERLAP_KEYS),
                 "queues_in_every_broadcast": bool(m._SYNC_QUEUES)}
 
 

@@ -22,6 +22,7 @@ import weakref
 import torch
 
 from . import ops
+from . import plan as _plan
 
 
 _PACK_STORE = {}      # id(weight) -> (weakref, {use -> packed buffer})
@@ -76,6 +77,16 @@ DEFERRED = [0]        # nodes that left the stream un-joined (tests / bench read
 # joined the stream on the main one.  Read -- and consumed -- by the bucket hook (coclr_amd/parallel.py).
 _SIDE_EVENTS = {}
 _CALLBACK_QUEUED = {}  # device -> an end-of-backward join has been queued for the running backward pass
+
+
+def _note(fn):
+    """Run `fn` (a stream dependency, a table update: something a pass does beside its C-ABI calls) now and, when
+    this thread is recording a launch plan (coclr_amd/plan.py), again at the same place of every replay."""
+    fn()
+    if _plan._ACTIVE is not None:
+        rec = _plan.active()
+        if rec is not None:
+            rec.py(fn)
 
 
 def side_stream_of(device):
@@ -404,6 +415,8 @@ class Run:
 
     def add_param_grad(self, p, g):
         old = self.param_grads.get(id(p))
+        if old is not None and _plan._ACTIVE is not None and _plan.active() is not None:
+            _plan.active().taint("a parameter used twice in one pass (its gradients are added by an ATen launch)")
         self.param_grads[id(p)] = g if old is None else old.add_(g)
 
     # -- lanes: independent sub-graphs (inception branches) on their own streams ------
@@ -479,7 +492,8 @@ class Run:
         st = _SIDE.get(self.device)
         if st is None:
             st = _SIDE[self.device] = torch.cuda.Stream(device=self.device, priority=_SIDE_PRIORITY)
-        st.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        _note(lambda st=st, cur=cur: st.wait_stream(cur))
         # Everything the side kernels read (the gradient dy AND the saved activation x) stays
         # referenced until join_side(): once a closure is popped its tensors would otherwise go
         # back to the main stream's allocator pool and could be handed out again while a lagging
@@ -490,8 +504,12 @@ class Run:
         # references (one event query per window, so the host cost stays negligible while the
         # peak is activations + a few windows of dy instead of activations + ALL dy).
         self._side_calls += 1
+        # (never while a launch plan is recorded: a release justified by an event QUERY is a fact about this
+        # pass's timing; the addresses it frees would be re-used by the plan at every replay, whose weight-
+        # gradient stream may lag further behind)
         if _SIDE_WINDOW and self._side_calls % _SIDE_WINDOW == 0 and self._side_keep and \
-                not torch.cuda.is_current_stream_capturing():
+                not torch.cuda.is_current_stream_capturing() and \
+                not (_plan._ACTIVE is not None and _plan.active() is not None):
             ev = torch.cuda.Event()
             ev.record(st)
             self._side_windows.append((ev, self._side_keep))
@@ -503,13 +521,21 @@ class Run:
         return st
 
     def join_side(self):
-        pending = _PENDING_SIDE.pop(self.device, None)
+        pending = _PENDING_SIDE.get(self.device)
         if self._side_used or pending:
-            torch.cuda.current_stream(self.device).wait_stream(_SIDE[self.device])
+            dev, keys = self.device, tuple(self.param_grads)
+
+            def join(dev=dev, keys=keys):
+                _PENDING_SIDE.pop(dev, None)
+                torch.cuda.current_stream(dev).wait_stream(_SIDE[dev])
+                if _SIDE_EVENTS:
+                    for k in keys:
+                        _SIDE_EVENTS.pop(k, None)         # ordered by the main stream from here on
+            _note(join)
             self._side_used = False
-        if _SIDE_EVENTS:
+        elif _SIDE_EVENTS:
             for k in self.param_grads:
-                _SIDE_EVENTS.pop(k, None)         # ordered by the main stream from here on
+                _SIDE_EVENTS.pop(k, None)
         self._side_keep = []
         self._side_windows = []
 
@@ -535,16 +561,19 @@ class Run:
         self._side_used = False
         # one event behind this node's weight gradients: the bucket hook waits for the events of the
         # parameters in ITS bucket instead of for everything queued on the stream by then
-        ev = torch.cuda.Event()
-        ev.record(_SIDE[self.device])
-        for k in self.param_grads:
-            _SIDE_EVENTS[k] = ev
         # ... and whoever runs last joins: the last node (stage 1) does it itself (join_side); if that one
         # deferred too, or never runs, the end-of-pass callback does
-        if not _CALLBACK_QUEUED.get(self.device):
-            _CALLBACK_QUEUED[self.device] = True
-            dev = self.device
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(dev))
+        dev, keys = self.device, tuple(self.param_grads)
+
+        def publish(dev=dev, keys=keys):
+            ev = torch.cuda.Event()
+            ev.record(_SIDE[dev])
+            for k in keys:
+                _SIDE_EVENTS[k] = ev
+            if not _CALLBACK_QUEUED.get(dev):
+                _CALLBACK_QUEUED[dev] = True
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(dev))
+        _note(publish)
 
     # -- weight packing ------------------------------------------------------------
     def _packed_buffer(self, owner, tag, n, zero):
@@ -1447,6 +1476,197 @@ def _capture_backward(ent, dout):
         _STATIC_PTRS.add(dx.data_ptr())
 
 
+# ---------------------------------------------------------------------------------
+# Launch-plan replay of a DIFFERENTIATED pass (coclr_amd/plan.py)
+# ---------------------------------------------------------------------------------
+# Same idea as the hipGraph replay above -- the launch sequence of a node is static per signature -- without
+# its device-side cost: the recorded C-ABI calls are re-issued as ordinary launches on the ordinary streams.
+# After _PLAN_WARMUP interpreted passes with an unchanged signature the node's forward is run once more with
+# its allocations in a private torch.cuda.MemPool while every call it makes is logged; its tape is kept (the
+# tensors it references now have addresses nobody else is given) and logged the same way at the first backward.
+# From then on a step of the node is: patch the two places that hold the input's address if the caller's
+# tensor moved, re-issue the forward log; copy dout into its recorded place, re-issue the backward log, hand
+# autograd fresh aliases of the recorded gradient tensors (DDP bucket views where DDP has them).
+# COCLR_PLAN=0 switches it off (the interpreted pass); hipGraph replay (COCLR_GRAPH_QUERY) takes precedence.
+PLAN = os.environ.get("COCLR_PLAN", "1") != "0"
+_PLAN_WARMUP = 4            # interpreted passes first: one-time allocations, DDP's bucket rebuild, slot verification
+PLAN_STATS = {"recorded": 0, "replayed": 0, "disabled": []}
+
+
+class _PlanEntry:
+    __slots__ = ("sig", "seen", "pool", "fwd", "bwd", "run", "xin", "x_ptr", "x_span", "x_refs", "x_fixed",
+                 "out", "dout", "grads", "dx", "params", "need_dx", "version", "disabled", "static_dout", "defer",
+                 "stream")
+
+    def __init__(self, sig):
+        self.sig, self.seen = sig, 0
+        self.pool = self.fwd = self.bwd = self.run = self.xin = None
+        self.x_ptr = self.x_span = 0
+        self.x_refs, self.x_fixed = None, False
+        self.out = self.dout = self.grads = self.dx = None
+        self.params, self.need_dx = (), False
+        self.version = 0
+        self.disabled = False
+        self.static_dout = None
+        self.defer = False
+        self.stream = 0
+
+
+def _plan_signature(module, x, params):
+    return _graph_signature(module, x, params, {}) + (
+        tuple(x.stride()), WGRAD_STREAM, DEFER_JOIN, PAIR_UNITS, FUSE_BN_REDUCE, LAZY_APPLY, POOLED_BACKWARD,
+        BATCH_PACK, tuple(id(p) in _SLOTS_VERIFIED for p in params))
+
+
+def _plan_drop(ent):
+    for t in (ent.out, ent.dx):
+        if t is not None:
+            _STATIC_PTRS.discard(t.data_ptr())
+
+
+def _plan_entry(module, x, params, kwargs):
+    """The node's plan entry when this call can go through it (recording or replaying), else None."""
+    if kwargs or not x.is_cuda or x.dim() != 5 or not _dense5(x) or LANES or DECISION_PROBE is not None or \
+            torch.cuda.is_current_stream_capturing():
+        return None
+    store = module.__dict__.get("_coclr_plan_entries")
+    if store is None:
+        store = module.__dict__["_coclr_plan_entries"] = {}
+    sig = _plan_signature(module, x, params)
+    key = (tuple(x.shape), bool(x.requires_grad))
+    ent = store.get(key)
+    if ent is None or ent.sig != sig:
+        if ent is not None:
+            _plan_drop(ent)
+        ent = store[key] = _PlanEntry(sig)       # new shape / moved storage / switches changed: start over
+    if ent.disabled:
+        return None
+    ent.seen += 1
+    if ent.seen <= _PLAN_WARMUP:
+        return None
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    if ent.fwd is not None:
+        if stream != ent.stream:
+            return None                          # recorded on another stream: this call runs interpreted
+        if x.data_ptr() != ent.x_ptr and (ent.x_fixed or ent.run is not None):
+            # the input moved and the logs cannot follow it: an address inside a multi-problem table, or a tape
+            # that has not been logged yet (forward recorded, no backward since) and reads the input through
+            # its own tensor objects.  This call runs interpreted.
+            return None
+    return ent
+
+
+def _record_forward(ent, module, x, defer):
+    dev = x.device
+    need_dx = bool(x.requires_grad)
+    ent.pool = torch.cuda.MemPool()
+    ent.stream = torch.cuda.current_stream(dev).cuda_stream
+    rec = _plan.Recorder(ent.stream)
+    with torch.cuda.use_mem_pool(ent.pool, device=dev), rec:
+        run = Run(dev, save=True, need_input_grad=need_dx)
+        xin = Val(x.detach())
+        if not need_dx:
+            run.no_grad_bases.add(id(xin.base))
+        run.begin(module)
+        run.out = module._emit(run, xin)
+        out = run.out.view()
+        if not out.is_contiguous():
+            rec.taint("the node's output is a channel slice")
+            out = out.contiguous()
+    n, c, t, h, w = x.shape
+    ent.x_ptr = x.data_ptr()
+    ent.x_span = ((n - 1) * x.stride(0) + c * t * h * w) * x.element_size()
+    ent.fwd, ent.run, ent.xin, ent.out = rec.plan, run, xin, out
+    ent.params, ent.need_dx, ent.defer = None, need_dx, defer
+    ent.x_refs = [rec.plan.pointer_refs(ent.x_ptr, ent.x_ptr + ent.x_span), None]
+    ent.x_fixed = rec.plan.embedded_refs(ent.x_ptr, ent.x_ptr + ent.x_span)
+    if rec.tainted:
+        ent.disabled = True
+        PLAN_STATS["disabled"].append(rec.tainted)
+    PLAN_STATS["recorded"] += 1
+    _STATIC_PTRS.add(out.data_ptr())
+
+
+def _record_backward(ent, dout, params):
+    dev = dout.device
+    if dout.is_contiguous() and dout.data_ptr() in _STATIC_PTRS:
+        static_dout, ent.static_dout = dout.detach(), True
+    else:
+        static_dout, ent.static_dout = None, None
+    run = ent.run
+    rec = _plan.Recorder(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.use_mem_pool(ent.pool, device=dev):
+        if static_dout is None:
+            static_dout = torch.empty(ent.out.shape, dtype=dout.dtype, device=dev)
+            static_dout.copy_(dout)
+        with rec:
+            run.backward(static_dout, defer_join=DEFER_JOIN and ent.defer)
+            dx = run.grads.pop(id(ent.xin.base), None) if ent.need_dx else None
+            grads = tuple(run.param_grads.pop(id(p), None) if p.requires_grad else None for p in params)
+            run.param_grads.clear()
+            run.grads.clear()
+    if rec.plan.stream != ent.stream:
+        rec.taint("backward ran on another stream than the forward")
+    ent.bwd, ent.dout, ent.grads, ent.dx = rec.plan, static_dout, grads, dx
+    ent.run = None           # the tape has been consumed; its tensors live on in the entry's pool
+    ent.x_refs[1] = rec.plan.pointer_refs(ent.x_ptr, ent.x_ptr + ent.x_span)
+    ent.x_fixed = ent.x_fixed or rec.plan.embedded_refs(ent.x_ptr, ent.x_ptr + ent.x_span)
+    if rec.tainted:
+        ent.disabled = True
+        PLAN_STATS["disabled"].append(rec.tainted)
+    if dx is not None:
+        _STATIC_PTRS.add(dx.data_ptr())
+
+
+class PlanFn(torch.autograd.Function):
+    """EngineFn whose forward and backward re-issue recorded launch plans (see PLAN)."""
+
+    @staticmethod
+    def forward(ctx, ent, module, x, *params):
+        new_pass(x.device)
+        if ent.fwd is None:
+            _record_forward(ent, module, x, getattr(module, "__dict__", {}).get("_coclr_defer_join", False))
+        else:
+            p = x.data_ptr()
+            if p != ent.x_ptr:
+                ent.fwd.patch(ent.x_refs[0], p)
+                if ent.bwd is not None:
+                    ent.bwd.patch(ent.x_refs[1], p)
+                ent.x_ptr = p
+            ent.fwd.replay()
+            PLAN_STATS["replayed"] += 1
+        ent.version += 1
+        ctx.ent, ctx.version, ctx.params = ent, ent.version, params
+        return ent.out.detach()
+
+    @staticmethod
+    def backward(ctx, dout):
+        ent = ctx.ent
+        if ctx.version != ent.version:
+            raise RuntimeError(
+                "coclr_amd: backward through a planned encoder pass whose activations a later forward has "
+                "overwritten (two forwards, then two backwards); set COCLR_PLAN=0")
+        ctx.ent = None
+        params = ctx.params
+        # a caller that accumulates gradients still holds last step's `.grad`, which aliases the recorded
+        # tensor this pass overwrites: give it its own memory first (rare: zero_grad() sets None)
+        if ent.grads is not None:
+            for p, g in zip(params, ent.grads):
+                if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                    p.grad = p.grad.clone()
+        if ent.bwd is None:
+            _record_backward(ent, dout, params)
+        else:
+            if torch.cuda.current_stream(dout.device).cuda_stream != ent.stream:
+                raise RuntimeError("coclr_amd: planned backward called on another stream than it was recorded on")
+            if ent.static_dout is None or dout.data_ptr() != ent.dout.data_ptr():
+                ent.dout.copy_(dout)
+            ent.bwd.replay()
+        grads = tuple(None if g is None else g.view_as(g) for g in ent.grads)
+        dx = ent.dx.view_as(ent.dx) if ent.dx is not None else None
+        return (None, None, dx) + grads
+
+
 def _dense5(t):
     n, c, d, h, w = t.shape
     s = t.stride()
@@ -1463,6 +1683,10 @@ def run_module(module, x, **kwargs):
             ent = _graph_entry(module, x, params, kwargs)
             if ent is not None:
                 return GraphedFn.apply(ent, x, *params)
+        elif PLAN:
+            ent = _plan_entry(module, x, params, kwargs)
+            if ent is not None:
+                return PlanFn.apply(ent, module, x, *params)
         return EngineFn.apply(module, kwargs, x, *params)
     run = Run(x.device, save=False)
     xin = Val(x if _dense5(x) else x.contiguous())

@@ -12,6 +12,7 @@ import threading
 import torch
 
 from . import _lib
+from . import plan as _plan
 from ._lib import BnBwdCall, BnFwdCall, ConvCall, ConvDesc, PoolDesc
 
 
@@ -33,10 +34,15 @@ def _desc(geom):
 
 
 def _L():
-    """ctypes handle, resolved once (every wrapper below runs ~1500 times per step)."""
+    """ctypes handle, resolved once (every wrapper below runs ~1500 times per step).  While THIS thread records a
+    launch plan (coclr_amd/plan.py) the handle is the recorder's proxy: every entry point runs and is logged."""
     global _HANDLE
     if _HANDLE is None:
         _HANDLE = _lib.load()
+    if _plan._ACTIVE is not None:
+        rec = _plan.active()
+        if rec is not None:
+            return rec.proxy
     return _HANDLE
 
 

@@ -230,6 +230,7 @@ def test_graphed_query_encoder_matches_eager(split, monkeypatch):
     from coclr_amd import engine
     from coclr_amd.backbone import s3dg
     late = split == "late"       # COCLR_GRAPH_QUERY=late: only Mixed_4b..5c replayed, the rest eager
+    monkeypatch.setattr(engine, "PLAN", False)     # the other run is the INTERPRETED pass
     monkeypatch.setattr(s3dg, "_SPLIT_MODE", "1" if split is True else "0")
     gold = load_golden("infonce_s3d_small")
     cfg = gold["cfg"]
@@ -260,6 +261,69 @@ def test_graphed_query_encoder_matches_eager(split, monkeypatch):
                 ents = list(m.__dict__["_coclr_graph_entries"].values())
                 assert any(e.fwd is not None and e.bwd is not None for e in ents), \
                     "the pass was never captured"
+        results.append((outs, [p.detach().clone() for p in model.parameters()],
+                        {k: v.clone() for k, v in model.state_dict().items()}))
+    (o_e, p_e, sd_e), (o_g, p_g, sd_g) = results
+    for step, (a, b) in enumerate(zip(o_e, o_g)):
+        assert torch.equal(a, b), "logits of step %d" % step
+    for a, b in zip(p_e, p_g):
+        assert torch.equal(a, b)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_planned_query_encoder_matches_eager(split, monkeypatch):
+    """COCLR_PLAN=1 (the default): after four interpreted passes the query encoder's forward and backward are
+    run once with their allocations in a private pool while every C-ABI call is logged (coclr_amd/plan.py), and
+    every later pass re-issues the logs -- ordinary launches on the ordinary streams with pre-marshalled
+    arguments.  Same kernels, same order, same operands: logits of every step and all parameters after ten
+    Adam steps must be BIT-identical to the interpreted run -- as one autograd node and as one node per
+    backbone stage.  The input is a new tensor every step (the recorded addresses of it are patched), step 7
+    runs a forward that no backward follows (main_coclr.py:403 until the queue is full), and the steps after the
+    recording must really have been replays."""
+    import copy
+    import torch.nn.functional as F
+    import model.pretrain as product
+    from coclr_amd import engine
+    from coclr_amd.backbone import s3dg
+    monkeypatch.setattr(s3dg, "_SPLIT_MODE", "1" if split else "0")
+    monkeypatch.setattr(engine, "GRAPH_QUERY", False)
+    monkeypatch.setattr(engine, "GRAPH_LATE", False)
+    gold = load_golden("infonce_s3d_small")
+    cfg = gold["cfg"]
+    base = build_model(cfg, product)
+    results = []
+    for planned in (False, True):
+        monkeypatch.setattr(engine, "PLAN", planned)
+        engine.PLAN_STATS.update(recorded=0, replayed=0, disabled=[])
+        model = copy.deepcopy(base).cuda().train()
+        opt = torch.optim.Adam([{"params": p} for _, p in model.named_parameters()], lr=1e-3,
+                               weight_decay=1e-5)
+        outs, held = [], []
+        for step in range(10):
+            blocks, _ = case_inputs(cfg, step % cfg["steps"])
+            torch.manual_seed(cfg["perm_seed"] + step)
+            x = blocks[0].cuda()
+            held.append(x)                   # keeps every input alive: each step's clip has its own address
+            out, tgt = model(x)
+            outs.append(out.detach().clone())
+            if step == 7:
+                continue                     # a forward nobody differentiates
+            loss = F.cross_entropy(out, tgt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        if planned:
+            mods = [model.encoder_q[0]] if not split else model.encoder_q[0]._stage_groups()
+            for m in mods:
+                ents = list(m.__dict__["_coclr_plan_entries"].values())
+                assert any(e.fwd is not None and e.bwd is not None and not e.disabled for e in ents), \
+                    "the pass was never recorded"
+            n = len(mods)
+            assert engine.PLAN_STATS["disabled"] == []
+            assert engine.PLAN_STATS["recorded"] == n and engine.PLAN_STATS["replayed"] == 5 * n, engine.PLAN_STATS
         results.append((outs, [p.detach().clone() for p in model.parameters()],
                         {k: v.clone() for k, v in model.state_dict().items()}))
     (o_e, p_e, sd_e), (o_g, p_g, sd_g) = results
