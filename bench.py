@@ -278,7 +278,7 @@ def cross_rank_check(model, out, device, world):
                     "query / key parameters, all-gathered and compared with rank 0's"}
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, threads=None, steps=None):
     """Time the CPU oracle (plain-PyTorch restatement of the reference step, pinned to the
     reference by tests/golden) on BASELINE.json configs[0]: B=4, K=2048, 3x32x128x128."""
     import torch.nn.functional as F
@@ -286,14 +286,15 @@ def cpu_baseline(args):
     from model.pretrain import InfoNCE
     from coclr_amd.optim import _TorchAdam
     B, K = 4, 2048
-    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+    torch.set_num_threads(max(1, min(threads or args.cpu_threads, os.cpu_count() or 1)))
     torch.manual_seed(0)
     model = InfoNCE(args.net, 128, K, 0.999, 0.07)
     sd = orc.training_state(model.state_dict())
     leaves = [sd[k] for k, _ in model.named_parameters() if sd[k].requires_grad]
     opt = _TorchAdam([{"params": p} for p in leaves], lr=1e-3, weight_decay=1e-5)
     times = []
-    for step in range(1 + args.cpu_steps):
+    nsteps = steps or args.cpu_steps
+    for step in range(1 + nsteps):
         g = torch.Generator().manual_seed(100 + step)
         block = torch.randn(B, 2, 3, args.seq_len, args.img_dim, args.img_dim, generator=g)
         perm = torch.randperm(B, generator=g)
@@ -310,12 +311,37 @@ def cpu_baseline(args):
             "kind": "port",
             "sample": "%d timed steps (1 warm-up) of S3D InfoNCE K=2048 B=4 3x%dx%dx%d fwd+bwd+Adam "
                       "through oracle/coclr_oracle.py (the reference's ATen CPU kernels) on %d of "
-                      "this host's %d hardware threads, %.2f s/step; the port against the reference's OWN "
-                      "module on one host, alternating, same threads: time ratio 1.010, identical losses "
-                      "(profiles/r05_cpu_port_vs_reference.txt, tools/cpu_port_vs_reference.py -- the "
-                      "reference itself does not exist on the GPU box)"
+                      "this host's %d hardware threads, %.2f s/step; how the port compares with the "
+                      "reference's OWN module on one host is measured by tools/cpu_port_vs_reference.py "
+                      "(profiles/r05_cpu_port_vs_reference.txt) -- the reference itself does not exist on "
+                      "the GPU box"
                       % (len(times), args.seq_len, args.img_dim, args.img_dim,
                          torch.get_num_threads(), os.cpu_count() or 0, dt)}
+
+
+def csrc_sha16():
+    """Hash of the kernel sources of THIS build: counter files under profiles/ carry the hash of the build they
+    were collected on (tools/traffic_json.py, tools/pmc_step_table.py) and are refused for any other."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "coclr_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counters_file(suffix):
+    """(json, None) of the newest profiles/rNN_<suffix> collected on this build's kernels, or (None, why)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)), reverse=True)
+    if not cands:
+        return None, "no profiles/rNN_%s" % suffix
+    tj = json.load(open(cands[0]))
+    if tj.get("csrc_sha16") != csrc_sha16():
+        return None, "%s was collected on other kernel sources (csrc %s, this build %s): re-run the PMC passes" % (
+            os.path.basename(cands[0]), tj.get("csrc_sha16"), csrc_sha16())
+    return tj, None
 
 
 def nce_roofline(device, B):
@@ -857,21 +883,20 @@ def measure(args, world):
         issued = flops * 16.0 / 36.0 if wino else flops         # F(2x2,3x3): 16 of 36 products
         roof = None
         traffic = None
-        tpath = next((t for t in (os.path.join(ROOT, "profiles", tag + "_traffic.json")
-                                  for tag in ("r05", "r04", "r03", "r02")) if os.path.exists(t)), "")
-        if os.path.exists(tpath) and args.net == "s3d" and B == 32:
-            # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
-            # (counters cannot be read from inside the process)
-            tj = json.load(open(tpath))
-            if ("wino" in tj["kernel"]) == wino:
+        traffic_note = None
+        if args.net == "s3d" and B == 32:
+            # HBM bytes per launch of this kernel from the PMC passes committed under profiles/ (counters cannot
+            # be read from inside the process) -- only when they were collected on THIS build's kernel sources
+            tj, traffic_note = counters_file("traffic.json")
+            if tj is not None and ("wino" in tj["kernel"]) == wino:
                 traffic = {"bytes_per_launch": tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"],
                            "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
-                           "source": tj["source"]}
+                           "mfma_busy_frac": tj.get("mfma_busy_frac"), "source": tj["source"]}
         if kms:
             ach = issued / (kms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": traffic,
+                    "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": "%s (Conv_2c.conv1 64->192, %dx%dx%d, N=%d; the query encoder's forward "
                               "launches inside the timed steps, sharing the chip with the key-encoder "
                               "stream)" % (dominant_kernel_name(dom_algo), tq, hq, hq, B),
@@ -911,7 +936,19 @@ def measure(args, world):
         step_view = None
         if per is not None and args.seq_len == 32 and args.img_dim == 128:
             gf, mb = per
-            step_view = {"gflop_per_sample": gf, "mb_per_sample": mb,
+            pmc, pmc_note = counters_file("step_pmc.json") if (args.net, args.model, B) == ("s3d", "infonce", 32) \
+                else (None, "counters are collected on the benchmark configuration only")
+            step_view = {"mfma_issued_frac": None if pmc is None else round(
+                             pmc["mfma_issued_gflop_per_step"] * 1e9 / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "mfma_issued_gflop_per_step": None if pmc is None else pmc["mfma_issued_gflop_per_step"],
+                         "hbm_counter_gbs": None if pmc is None else round(
+                             (pmc["hbm_fetch_mb_per_step"] + pmc["hbm_write_mb_per_step"]) * 1e6 / (ms * 1e-3) / 1e9, 1),
+                         "counters": pmc_note or pmc["source"],
+                         "what": "mfma_issued_frac = MFMA FLOPs the step's kernels ISSUE (SQ_INSTS_VALU_MFMA_MOPS_F32 "
+                                 "x 512 summed over one step, Winograd forms counted as what they issue) / this "
+                                 "run's step time / 157.3 TF; frac_fp32_peak below is in direct-convolution-"
+                                 "equivalent FLOPs and flatters by the Winograd factor",
+                         "gflop_per_sample": gf, "mb_per_sample": mb,
                          "tflops_per_gpu": round(gf * 1e9 * B / (ms * 1e-3) / 1e12, 2),
                          "frac_fp32_peak": round(gf * 1e9 * B / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                          "algorithmic_gbs_per_gpu": round(mb * 1e6 * B / (ms * 1e-3) / 1e9, 1),
@@ -978,6 +1015,15 @@ def measure(args, world):
             rec["value_k16384"] = k16
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args)
+            # SURVEY 8d asks for the reference's CPU path on the box's host cores: the same oracle step on EVERY
+            # hardware thread the host has (slower than 16 on the 256-thread GPU host: oversubscribed ATen
+            # convolutions), beside the fastest thread count above
+            ncpu = os.cpu_count() or 1
+            if ncpu > rec["cpu_baseline"]["cores"]:
+                allc = cpu_baseline(args, threads=ncpu, steps=2)
+                rec["cpu_baseline_all_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "kind")}
+                rec["cpu_baseline_all_cores"]["sample"] = "the same oracle step, 2 timed steps, on all %d hardware " \
+                                                          "threads of this host" % ncpu
 
     # ---- N > 1: host floor of the per-stage structure; optional -- a hang here must not cost the record --
     if world > 1 and args.model == "infonce" and B >= 16 and K % (4 * world) == 0:

@@ -53,6 +53,18 @@ def condition_model(model, cond):
             wk = torch.randn(sd[k].shape, generator=g) * (2.0 / fan_in) ** 0.5
             sd[k].copy_(w)
             sd["encoder_k." + k[len("encoder_q."):]].copy_(wk)
+        # CoCLR's frozen sampler (model/pretrain.py:296-302), drawn AFTER everything above so that the
+        # InfoNCE fixtures keep their weights: He-normal too, or its features -- and with them the
+        # cross-modal top-k of :405-410 -- would sit at round-off level
+        done = set()
+        for k in list(sd.keys()):
+            if not k.startswith("sampler.") or sd[k].dim() != 5 or not k.endswith("weight"):
+                continue
+            if sd[k].data_ptr() in done:
+                continue
+            done.add(sd[k].data_ptr())
+            fan_in = sd[k].shape[1] * sd[k].shape[2] * sd[k].shape[3] * sd[k].shape[4]
+            sd[k].copy_(torch.randn(sd[k].shape, generator=g) * (2.0 / fan_in) ** 0.5)
     return model
 
 
@@ -70,6 +82,8 @@ def build_model(cfg, module):
         model = module.UberNCE(*args)
     else:
         model = module.CoCLR(*args, topk=cfg["topk"], reverse=cfg.get("reverse", False))
+        if cfg.get("condition"):
+            condition_model(model, cfg["condition"])
         if cfg.get("prefill"):
             g = torch.Generator().manual_seed(cfg["prefill"])
             model.queue_label.fill_(1)

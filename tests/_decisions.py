@@ -129,7 +129,9 @@ def oracle_grads(state_dict, cfg, blocks, extra, perm, dtype=torch.float32, deci
     real_bn = orc._bn
 
     def bn(sd_, pre, x, training):
-        if x.requires_grad:
+        # the ReLU of a ResNet bottleneck follows bn3 + residual (backbone/resnet_2d3d.py:82-86): the
+        # BatchNorm of the downsample path in between (:79-80) is not the unit it belongs to
+        if x.requires_grad and ".downsample." not in pre:
             proxy.cur = pre
         return real_bn(sd_, pre, x, training)
 

@@ -17,7 +17,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from _cases import build_model, case_inputs, check_close, load_golden
+from _cases import build_model, case_inputs, check_close, load_golden, loss_fn
 from _decisions import l2_table, oracle_grads, product_grads, record_product
 
 pytestmark = pytest.mark.gpu
@@ -43,11 +43,14 @@ def _median(vals):
     return vals[len(vals) // 2]
 
 
-def _product_step(model, block, perm_seed):
+def _product_step(model, block, perm_seed, kind="infonce", block2=None, extra=None):
     def step():
         torch.manual_seed(perm_seed)
-        out, tgt = model(block.cuda())
-        loss = F.cross_entropy(out, tgt)
+        if kind == "coclr":
+            out, tgt = model(block.cuda(), block2.cuda(), extra.cuda())
+        else:
+            out, tgt = model(block.cuda())
+        loss = loss_fn(kind, out, tgt)
         loss.backward()
         torch.cuda.synchronize()
         return out.detach().cpu(), float(loss.detach())
@@ -167,3 +170,64 @@ def test_config2_backbone_gradients_at_benchmarked_size():
             lambda: oracle_grads(sd0, cfg, blocks, extra, perm, torch.float64, decisions=dec))
         print("B=32: float64 oracle %.0f s" % (time.time() - t1))
         _hold(l2_table(got, g32, t64), "config 2 at B=32")
+
+
+def _benchmarked_size_case(cfg, n_tensors, what, decision_bar=2e-4, relu_bar=2e-5):
+    """One training step of `cfg` at B=32 on the GPU; every parameter gradient of the query encoder against the
+    fp32 oracle evaluated on the product's ReLU / max-pool decisions (the north star's 1e-3, per tensor, L2)."""
+    import model.pretrain as product
+    kind = cfg["kind"]
+    model = build_model(cfg, product)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    blocks, extra = case_inputs(cfg, 0)
+    torch.manual_seed(cfg["perm_seed"])
+    perm = torch.randperm(cfg["B"])
+    model = model.cuda().train()
+    if kind == "coclr":
+        model.sampler.eval()                              # main_coclr.py:363
+    (logits, loss), dec = _product_step(model, blocks[0], cfg["perm_seed"], kind,
+                                        blocks[1] if kind == "coclr" else None, extra)
+    got = product_grads(model)
+    del model
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    g32, l32, ref_logits, odec = _with_threads(
+        lambda: oracle_grads(sd0, cfg, blocks, extra, perm, torch.float32, decisions=dec))
+    t1 = time.time()
+    total = dec.count()
+    nd = sum(d for _, d, _ in odec.disagree)
+    print("%s: decisions the fp32 oracle would take differently: %d of %d (%.1e); largest: %s"
+          % (what, nd, total, nd / total, sorted(odec.disagree, key=lambda f: -f[1])[:4]))
+    assert nd <= decision_bar * total, (nd, total)
+    relu_only = sum(d for w, d, _ in odec.disagree if not w.startswith("pool#"))
+    assert relu_only <= relu_bar * total, (relu_only, total)
+    check_close(logits, ref_logits, 1e-3, "logits")
+    assert abs(loss - float(l32)) <= 1e-3 * max(1.0, abs(float(l32)))
+    assert set(got) == set(g32) and len(got) >= n_tensors, (len(got), len(g32), sorted(set(got) ^ set(g32))[:6])
+    direct = l2_table(got, got, g32)
+    worst = max(direct.items(), key=lambda kv: kv[1][0])
+    print("%s: %d tensors, product vs fp32 oracle on the product's decisions: median L2 %.2e, worst %.2e (%s); "
+          "oracle fp32 %.0f s" % (what, len(direct), _median(v[0] for v in direct.values()), worst[1][0], worst[0],
+                                  t1 - t0))
+    assert worst[1][0] <= 1e-3, worst
+
+
+def test_config5_r50_backbone_gradients_at_benchmarked_size():
+    """BASELINE config 5 at the benchmarked size (ResNet2d3d-50, B=32 clips of 3x32x128x128, K=16384) on a
+    conditioned model: EVERY parameter gradient of the query encoder -- the kernels S3D never launches
+    included: the strided (1,3,3) data gradient through zero-upsampling, the five-slice (5,7,7) stem, the
+    residual-add fusion, the strided pointwise downsample path (backbone/resnet_2d3d.py:67-86,138-141,191-202)
+    -- against the fp32 oracle on the product's decisions."""
+    cfg = dict(kind="infonce", network="r50", B=32, K=16384, dim=128, m=0.999, T=0.07,
+               clip=(3, 32, 128, 128), model_seed=0, input_seed=51, perm_seed=150, condition=dict(seed=19))
+    _benchmarked_size_case(cfg, 161, "config 5 (r50) at B=32")
+
+
+def test_config4_coclr_query_encoder_gradients_at_benchmarked_size():
+    """BASELINE config 4 at the benchmarked size (S3D CoCLR two-stream, B=32, K=2048, topk=5, queue full so that
+    the cross-modal mining of model/pretrain.py:403-413 shapes the loss) on a conditioned model: every
+    parameter gradient of the query encoder under the multi-positive loss of main_coclr.py:343-346."""
+    cfg = dict(kind="coclr", network="s3d", B=32, K=2048, dim=128, m=0.999, T=0.07, topk=5, n_sources=300,
+               prefill=5, clip=(3, 32, 128, 128), model_seed=0, input_seed=61, perm_seed=160,
+               condition=dict(seed=29))
+    _benchmarked_size_case(cfg, 235, "config 4 (CoCLR) at B=32")
