@@ -937,6 +937,685 @@ template <int CC, int BM, int BNP, int PCH, bool XV4, int OCC = 1>
 int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot = nullptr);
 
 // ------------------------------------------------------------------------------------
+// Temporal (3,1,1) stride-1 convolutions through Winograd F(4,3) along T (coclr_conv_desc.algo = 2).
+//
+// A QUAD of output frames (4p .. 4p+3) needs input frames d0..d5 = 4p-1 .. 4p+4 and SIX channel
+// contractions instead of twelve (F(2,3) above: eight):
+//     D0 = 4 d0 - 5 d2 + d4          D1 = (d4 - 4 d2) + (d3 - 4 d1)     D2 = (d4 - 4 d2) - (d3 - 4 d1)
+//     D3 = (d4 - d2) + 2 (d3 - d1)   D4 = (d4 - d2) - 2 (d3 - d1)       D5 = 4 d1 - 5 d3 + d5
+//     m_i = U_i D_i   (U0 = g0/4, U1 = -(g0+g1+g2)/6, U2 = -(g0-g1+g2)/6, U3 = g0/24 + g1/12 + g2/6,
+//                      U4 = g0/24 - g1/12 + g2/6, U5 = g2: [Cout][Cin] matrices, a 6-"tap" packed operand)
+//     y[4p]   = m0 + (m1 + m2) + (m3 + m4)        y[4p+1] = (m1 - m2) + 2 (m3 - m4)
+//     y[4p+2] = (m1 + m2) + 4 (m3 + m4)           y[4p+3] = (m1 - m2) + 8 (m3 - m4) + m5
+// (interpolation points 0, +-1, +-2, inf).  Everything stays fp32; against float64 the result carries ~3.5x the
+// rounding error of the direct fp32 convolution (L2 7e-7 against 2e-7 at 192 channels; F(2,3): 2.7e-7) --
+// three orders of magnitude inside the 1e-3 the path is held to.
+//
+// Same structure as conv_wino_t_body: a (6,1,1) stencil with temporal stride 4 over "quad positions", six
+// accumulator sets per 32x32 block (96 registers: three workgroups per CU), the epilogue emits four frames.
+// 2x fewer MFMAs than the direct form, 1.33x fewer than F(2,3).
+template <int CC, int BM, int BNQ, int PCH, bool XV4>
+__device__ __forceinline__ void conv_wino_t4_body(const ConvArgs& a, int bid, const int nblocks) {
+  constexpr int TAPS = 6;
+  constexpr int WM = 2, WN = 2;
+  constexpr int MF = BM / (WM * 32), NF = BNQ / (WN * 32);
+  constexpr int RPP = 256 / BM;
+  constexpr int WPIECES = TAPS * CC / RPP;
+  static_assert(CC % RPP == 0 && CC % 4 == 0, "chunk shape");
+  constexpr int W_FLOATS = TAPS * CC * BM;
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeS = a.planeS;
+  const int stage_floats = W_FLOATS + CC * planeS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  if (a.xcd) {                        // XCD-aware tile ids (see conv_igemm_body)
+    const int per = nblocks >> 3;
+    if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int mt = bid % a.mtiles;
+  const int ntile = bid / a.mtiles;
+  int r = ntile;
+  const int bw_ = r % a.nbw; r /= a.nbw;
+  const int bh_ = r % a.nbh; r /= a.nbh;
+  const int bt_ = r % a.nbt; r /= a.nbt;
+  const int n0 = r << a.lTN;
+  const int ow0 = bw_ << a.lTW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;   // ot0: QUAD index
+  const int cout0 = mt * BM;
+  const int vt0 = ot0 * 4 - 1, vh0 = oh0, vw0 = ow0;                      // window origin
+  const int plane = a.plane;
+
+  const float* xbase = a.x + (long)n0 * a.x_nstride;
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, BUF_RANGE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
+  float* ybase = a.y + (long)n0 * a.y_nstride;
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, BUF_RANGE, 0x00020000);
+
+  unsigned goff[XV4 ? 1 : PCH];
+  if (!XV4) {
+    const int hw = a.WH * a.WW;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int e = j * 64 + lane;
+      unsigned off = OOB;
+      if (e < plane) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
+        const int wh = fdiv(q, a.inv_ww);
+        const int ww = q - wh * a.WW;
+        const int n = n0 + wn_;
+        const int it = vt0 + wt, ih = vh0 + wh, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && ih < a.Hi && iw < a.Wi)
+          off = (unsigned)(((long)wn_ * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4);
+      }
+      goff[j] = off;
+    }
+  }
+  const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
+
+  // XV4: 16-byte DMA of the halo-free window, 1 KiB pieces across channel rows (see conv_wino_t_body)
+  constexpr int PV = (CC * PCH * 64 / 256 + 3) / 4;
+  unsigned xvoff[PV];
+  int xvc[PV];
+  if (XV4) {
+#pragma unroll
+    for (int jj = 0; jj < PV; ++jj) {
+      const int flat = (wave + 4 * jj) * 256 + lane * 4;
+      const int c = flat / plane, e = flat - c * plane;
+      unsigned off = OOB;
+      if (c < CC) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        const int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_ww);              // WH == 1 here
+        const int ww = q - wt * a.WW;
+        const int n = n0 + wn_, it = vt0 + wt, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && iw < a.Wi)
+          off = (unsigned)(((long)wn_ * a.x_nstride + (long)it * a.Wi + iw + (long)c * a.x_cstride) * 4);
+      }
+      xvoff[jj] = off;
+      xvc[jj] = c;
+    }
+  }
+
+  // quad position of this lane: window offset of its frame d0 (d1..d5 follow at +WH*WW each)
+  int lanebase[NF];
+  const int fstride = a.WH * a.WW;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BNQ / WN) + nf * 32 + l31;
+    const int tw = p & ((1 << a.lTW) - 1);
+    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    lanebase[nf] = W_FLOATS + tn * a.plane1 + ((tt * 4) * a.WH + th) * a.WW + tw + half * planeS;
+  }
+  const int abase = half * BM + wm * (BM / WM) + l31;
+
+  f32x16 acc[MF][NF][6];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mf][nf][t][i] = 0.f;
+
+  auto stage = [&](int cin0, float* sbase) {
+    for (int p = wave; p < WPIECES; p += 4) {
+      const int row0 = p * RPP;
+      const int tap = row0 / CC, c0 = row0 % CC;
+      const unsigned soff = (unsigned)((((long)tap * a.CinP + cin0 + c0) * a.CoutP + cout0) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sbase + p * 256), 16, wvoff, soff, 0, 0);
+    }
+    float* xs = sbase + W_FLOATS;
+    if (XV4) {
+      const unsigned soff = (unsigned)cin0 * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+      for (int jj = 0; jj < PV; ++jj) {
+        const int j = wave + 4 * jj;
+        if (j * 256 < CC * plane && xvc[jj] < CC) {   // exec-masked: lanes past the image write nothing
+          const unsigned vo = cin0 + xvc[jj] < a.Cin ? xvoff[jj] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + j * 256), 16, vo, soff, 0, 0);
+        }
+      }
+    } else
+#pragma unroll
+    for (int ci = 0; ci < CC / 4; ++ci) {
+      const int c = ci * 4 + wave;
+      const int cin = cin0 + c;
+      if (cin < a.Cin) {
+        const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
+                                                     goff[XV4 ? 0 : j], soff, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane) xs[c * planeS + j * 64 + lane] = 0.f;
+      }
+    }
+  };
+
+  const int nchunks = a.nchunks;
+  stage(0, smem);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* cur = smem + (ch & 1) * stage_floats;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((ch + 1) & 1) * stage_floats);
+
+    constexpr int QS = CC / 2;
+    // step q: channel pair (2q, 2q+1); operands of step q+1 are fetched under the MFMAs of q
+    auto fetch = [&](int q, float (&av)[MF][6], float (&dv)[NF][6]) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) av[mf][t] = cur[abase + (t * CC + 2 * q) * BM + mf * 32];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dv[nf][k] = cur[lanebase[nf] + k * fstride + 2 * q * planeS];
+    };
+    float av[2][MF][6], dv[2][NF][6];
+    fetch(0, av[0], dv[0]);
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      if (q + 1 < QS) fetch(q + 1, av[(q + 1) & 1], dv[(q + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const float d0 = dv[q & 1][nf][0], d1 = dv[q & 1][nf][1], d2 = dv[q & 1][nf][2],
+                    d3 = dv[q & 1][nf][3], d4 = dv[q & 1][nf][4], d5 = dv[q & 1][nf][5];
+        const float t1 = fmaf(-4.f, d2, d4), t2 = fmaf(-4.f, d1, d3);
+        const float u1 = d4 - d2, v = d3 - d1;
+        const float D[6] = {fmaf(4.f, d0, fmaf(-5.f, d2, d4)), t1 + t2, t1 - t2, fmaf(2.f, v, u1),
+                            fmaf(-2.f, v, u1), fmaf(4.f, d1, fmaf(-5.f, d3, d5))};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+            acc[mf][nf][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][mf][t], D[t],
+                                                                  acc[mf][nf][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: four frames per quad position ---------------------------------------------------
+  unsigned yvoff[NF];
+  int nvalid[NF];                 // valid frames of the quad (0 = position outside the tensor)
+  const unsigned half_rows = (unsigned)half * 4u * (unsigned)a.y_cstride * 4u;
+  const unsigned frame_bytes = (unsigned)(a.yHf * a.yWf) * 4u;
+  const int To_full = a.yst;     // launcher passes the un-grouped frame count here
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BNQ / WN) + nf * 32 + l31;
+    const int tw = p & ((1 << a.lTW) - 1);
+    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    const int n = n0 + tn, tp = ot0 + tt, oh = oh0 + th, ow = ow0 + tw;
+    const bool ok = n < a.N && 4 * tp < To_full && oh < a.Ho && ow < a.Wo;
+    int nv = To_full - 4 * tp;
+    nvalid[nf] = ok ? (nv > 4 ? 4 : nv) : 0;
+    const long e = (long)tn * a.y_nstride + ((long)(4 * tp) * a.yHf + oh) * a.yWf + ow;
+    yvoff[nf] = ok ? (unsigned)(e * 4) + half_rows : OOB;
+  }
+
+  const bool want_stats = a.stats != nullptr;
+  float* red = smem;
+  if (want_stats) __syncthreads();
+
+  auto emit = [&](auto acc_tag, auto fancy_tag) {       // FANCY: see conv_igemm_body
+    constexpr bool ACCUM = decltype(acc_tag)::value;
+    constexpr bool FANCY = decltype(fancy_tag)::value;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);
+        const int ml = rowu + 4 * half;
+        const int co = cout0 + ml;
+        const bool cok = co < a.Cout;
+        const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+        float s = 0.f, ss = 0.f;
+        float bia = 0.f, sc = 1.f, sf = 0.f;
+        if (FANCY) {
+          if (a.bias && cok) bia = a.bias[co];
+          if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const float m0 = acc[mf][nf][0][i], m1 = acc[mf][nf][1][i], m2 = acc[mf][nf][2][i],
+                      m3 = acc[mf][nf][3][i], m4 = acc[mf][nf][4][i], m5 = acc[mf][nf][5][i];
+          const float sa = m1 + m2, sb = m1 - m2, sc_ = m3 + m4, sd = m3 - m4;
+          float v[4] = {(m0 + sa) + sc_, fmaf(2.f, sd, sb), fmaf(4.f, sc_, sa), fmaf(8.f, sd, sb) + m5};
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            const bool fv = f < nvalid[nf];
+            const unsigned vo = (cok && fv) ? yvoff[nf] + (unsigned)f * frame_bytes : OOB;
+            if (ACCUM) v[f] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo, soff, 0));
+            const float u = fv ? v[f] : 0.f;
+            s += u; ss += u * u;
+            if (FANCY) {
+              v[f] = (v[f] + bia) * sc + sf;
+              if (a.relu) v[f] = fmaxf(v[f], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[f]), ry, vo, soff, 0);
+          }
+        }
+        if (want_stats) {
+          s = row16_sum(s);
+          ss = row16_sum(ss);
+          if ((lane & 15) == 0) {
+            const int slot = wn * 2 + (l31 >> 4);
+            red[(slot * BM + ml) * 2 + 0] = s;
+            red[(slot * BM + ml) * 2 + 1] = ss;
+          }
+        }
+      }
+    }
+  };
+  const bool fancy = a.bias || a.ep_scale || a.relu;
+  if (fancy) { if (a.accumulate) emit(std::true_type{}, std::true_type{}); else emit(std::false_type{}, std::true_type{}); }
+  else if (a.accumulate) emit(std::true_type{}, std::false_type{});
+  else emit(std::false_type{}, std::false_type{});
+
+  if (want_stats) {
+    __syncthreads();
+    if (tid < BM) {
+      const int co = cout0 + tid;
+      if (co < a.Cout) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s += red[(k * BM + tid) * 2];
+          ss += red[(k * BM + tid) * 2 + 1];
+        }
+        a.stats[(long)co * a.ntiles + ntile] = s;
+        a.stats[((long)a.Cout + co) * a.ntiles + ntile] = ss;
+      }
+    }
+  }
+}
+
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC)
+conv_wino_t4_kernel(const ConvArgs a) {
+  conv_wino_t4_body<CC, BM, BNQ, PCH, XV4>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// two problems in one launch, see conv_igemm_pair_kernel
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC)
+conv_wino_t4_pair_kernel(const ConvArgs a0, const ConvArgs a1, const int nb0) {
+  if ((int)blockIdx.x < nb0) conv_wino_t4_body<CC, BM, BNQ, PCH, XV4>(a0, (int)blockIdx.x, nb0);
+  else conv_wino_t4_body<CC, BM, BNQ, PCH, XV4>(a1, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+}
+
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC>
+int wino_t4_single(const ConvArgs& a, long blocks, size_t lds, hipStream_t stream) {
+  auto kern = conv_wino_t4_kernel<CC, BM, BNQ, PCH, XV4, OCC>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC>
+int wino_t4_pair(const ConvArgs& a0, const ConvArgs& a1, long b0, long b1, size_t lds, hipStream_t stream) {
+  auto kern = conv_wino_t4_pair_kernel<CC, BM, BNQ, PCH, XV4, OCC>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b0 + b1)), dim3(256), lds, stream, a0, a1, (int)b0);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC = 1>
+int launch_wino_t4(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot = nullptr);
+
+// ------------------------------------------------------------------------------------
+// The temporal stem conv (7,1,1) / stride 2 / pad 3 (STConv3d's second half in Conv_1a, backbone/s3dg.py:41,145)
+// in POLYPHASE Winograd form (coclr_conv_desc.algo = 1 on that stencil).
+//
+// y[t] = sum_k w[k] x[2t + k - 3].  With stride 2 the odd taps (w1, w3, w5) only ever meet one parity of input
+// frames and the even taps (w0, w2, w4, w6) the other: for a PAIR of outputs (2p, 2p+1) and the window
+// r_j = x[4p - 3 + j], j = 0..8,
+//     y[2p]   = (w1 r1 + w3 r3 + w5 r5)  +  (w0 r0 + w2 r2 + w4 r4 + w6 r6)
+//     y[2p+1] = (w1 r3 + w3 r5 + w5 r7)  +  (w0 r2 + w2 r4 + w4 r6 + w6 r8)
+// i.e. a 3-tap stride-1 correlation over e = (r1, r3, r5, r7) plus a 4-tap one over o = (r0, r2, r4, r6, r8):
+// F(2,3) (4 products) + F(2,4) (5 products, points 0, 1, -1, 2, inf) = NINE channel contractions per output
+// pair instead of fourteen:
+//     E = (e0-e2, e1+e2, e2-e1, e1-e3)                          U_e = (a0, (a0+a1+a2)/2, (a0-a1+a2)/2, a2)
+//     O = (2(o0-o2)+(o3-o1), -2o1-o2+o3, 2o1-3o2+o3, o3-o1, 2(o1-o3)+(o4-o2))
+//     U_o = (b0/2, -(b0+b1+b2+b3)/2, (-b0+b1-b2+b3)/6, (b0+2b1+4b2+8b3)/6, b3)
+//     y[2p] = (m0+m1+m2) + (n0+n1+n2+n3)        y[2p+1] = (m1-m2-m3) + (n1-n2+2n3+n4)
+// Same structure as the temporal Winograd kernels above: a (9,1,1) stencil with temporal stride 4 over output-pair
+// positions, nine accumulator sets per 32x32 block (144 registers: two workgroups per CU).
+template <int CC, int BM, int BNQ, int PCH, bool XV4>
+__device__ __forceinline__ void conv_poly7_body(const ConvArgs& a, int bid, const int nblocks) {
+  constexpr int TAPS = 9;
+  constexpr int WM = 2, WN = 2;
+  constexpr int MF = BM / (WM * 32), NF = BNQ / (WN * 32);
+  constexpr int RPP = 256 / BM;
+  constexpr int WPIECES = TAPS * CC / RPP;
+  static_assert(CC % RPP == 0 && CC % 4 == 0, "chunk shape");
+  constexpr int W_FLOATS = TAPS * CC * BM;
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeS = a.planeS;
+  const int stage_floats = W_FLOATS + CC * planeS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  if (a.xcd) {                        // XCD-aware tile ids (see conv_igemm_body)
+    const int per = nblocks >> 3;
+    if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int mt = bid % a.mtiles;
+  const int ntile = bid / a.mtiles;
+  int r = ntile;
+  const int bw_ = r % a.nbw; r /= a.nbw;
+  const int bh_ = r % a.nbh; r /= a.nbh;
+  const int bt_ = r % a.nbt; r /= a.nbt;
+  const int n0 = r << a.lTN;
+  const int ow0 = bw_ << a.lTW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;   // ot0: output-PAIR index
+  const int cout0 = mt * BM;
+  const int vt0 = ot0 * 4 - 3, vh0 = oh0, vw0 = ow0;                      // window origin: frame 4p - 3
+  const int plane = a.plane;
+
+  const float* xbase = a.x + (long)n0 * a.x_nstride;
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, BUF_RANGE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
+  float* ybase = a.y + (long)n0 * a.y_nstride;
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, BUF_RANGE, 0x00020000);
+
+  unsigned goff[XV4 ? 1 : PCH];
+  if (!XV4) {
+    const int hw = a.WH * a.WW;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int e = j * 64 + lane;
+      unsigned off = OOB;
+      if (e < plane) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
+        const int wh = fdiv(q, a.inv_ww);
+        const int ww = q - wh * a.WW;
+        const int n = n0 + wn_;
+        const int it = vt0 + wt, ih = vh0 + wh, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && ih < a.Hi && iw < a.Wi)
+          off = (unsigned)(((long)wn_ * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4);
+      }
+      goff[j] = off;
+    }
+  }
+  const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
+
+  // XV4: 16-byte DMA of the halo-free window, 1 KiB pieces across channel rows (see conv_wino_t_body)
+  constexpr int PV = (CC * PCH * 64 / 256 + 3) / 4;
+  unsigned xvoff[PV];
+  int xvc[PV];
+  if (XV4) {
+#pragma unroll
+    for (int jj = 0; jj < PV; ++jj) {
+      const int flat = (wave + 4 * jj) * 256 + lane * 4;
+      const int c = flat / plane, e = flat - c * plane;
+      unsigned off = OOB;
+      if (c < CC) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        const int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_ww);              // WH == 1 here
+        const int ww = q - wt * a.WW;
+        const int n = n0 + wn_, it = vt0 + wt, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && iw < a.Wi)
+          off = (unsigned)(((long)wn_ * a.x_nstride + (long)it * a.Wi + iw + (long)c * a.x_cstride) * 4);
+      }
+      xvoff[jj] = off;
+      xvc[jj] = c;
+    }
+  }
+
+  // pair position of this lane: window offset of its frame r0 (r1..r8 follow at +WH*WW each)
+  int lanebase[NF];
+  const int fstride = a.WH * a.WW;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BNQ / WN) + nf * 32 + l31;
+    const int tw = p & ((1 << a.lTW) - 1);
+    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    lanebase[nf] = W_FLOATS + tn * a.plane1 + ((tt * 4) * a.WH + th) * a.WW + tw + half * planeS;
+  }
+  const int abase = half * BM + wm * (BM / WM) + l31;
+
+  f32x16 acc[MF][NF][9];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mf][nf][t][i] = 0.f;
+
+  auto stage = [&](int cin0, float* sbase) {
+    for (int p = wave; p < WPIECES; p += 4) {
+      const int row0 = p * RPP;
+      const int tap = row0 / CC, c0 = row0 % CC;
+      const unsigned soff = (unsigned)((((long)tap * a.CinP + cin0 + c0) * a.CoutP + cout0) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sbase + p * 256), 16, wvoff, soff, 0, 0);
+    }
+    float* xs = sbase + W_FLOATS;
+    if (XV4) {
+      const unsigned soff = (unsigned)cin0 * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+      for (int jj = 0; jj < PV; ++jj) {
+        const int j = wave + 4 * jj;
+        if (j * 256 < CC * plane && xvc[jj] < CC) {   // exec-masked: lanes past the image write nothing
+          const unsigned vo = cin0 + xvc[jj] < a.Cin ? xvoff[jj] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + j * 256), 16, vo, soff, 0, 0);
+        }
+      }
+    } else
+#pragma unroll
+    for (int ci = 0; ci < CC / 4; ++ci) {
+      const int c = ci * 4 + wave;
+      const int cin = cin0 + c;
+      if (cin < a.Cin) {
+        const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
+                                                     goff[XV4 ? 0 : j], soff, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane) xs[c * planeS + j * 64 + lane] = 0.f;
+      }
+    }
+  };
+
+  const int nchunks = a.nchunks;
+  stage(0, smem);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* cur = smem + (ch & 1) * stage_floats;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((ch + 1) & 1) * stage_floats);
+
+    constexpr int QS = CC / 2;
+    // step q: channel pair (2q, 2q+1); operands of step q+1 are fetched under the MFMAs of q
+    auto fetch = [&](int q, float (&av)[MF][9], float (&dv)[NF][9]) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) av[mf][t] = cur[abase + (t * CC + 2 * q) * BM + mf * 32];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dv[nf][k] = cur[lanebase[nf] + k * fstride + 2 * q * planeS];
+    };
+    float av[2][MF][9], dv[2][NF][9];
+    fetch(0, av[0], dv[0]);
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      if (q + 1 < QS) fetch(q + 1, av[(q + 1) & 1], dv[(q + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const float* r_ = dv[q & 1][nf];
+        // odd taps (w1, w3, w5) on frames r1, r3, r5, r7: F(2,3); even taps (w0, w2, w4, w6) on r0, r2, r4, r6, r8: F(2,4)
+        const float e0 = r_[1], e1 = r_[3], e2 = r_[5], e3 = r_[7];
+        const float o0 = r_[0], o1 = r_[2], o2 = r_[4], o3 = r_[6], o4 = r_[8];
+        const float oa = o3 - o2, o31 = o3 - o1;
+        const float D[9] = {e0 - e2, e1 + e2, e2 - e1, e1 - e3,
+                            fmaf(2.f, o0 - o2, o31), fmaf(-2.f, o1, oa), fmaf(2.f, o1, fmaf(-2.f, o2, oa)), o31,
+                            fmaf(-2.f, o31, o4 - o2)};
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+            acc[mf][nf][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][mf][t], D[t],
+                                                                  acc[mf][nf][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: two frames per pair position -----------------------------------------------------
+  unsigned yvoff[NF];
+  int nvalid[NF];                 // valid frames of the pair (0 = position outside the tensor)
+  const unsigned half_rows = (unsigned)half * 4u * (unsigned)a.y_cstride * 4u;
+  const unsigned frame_bytes = (unsigned)(a.yHf * a.yWf) * 4u;
+  const int To_full = a.yst;     // launcher passes the un-grouped frame count here
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BNQ / WN) + nf * 32 + l31;
+    const int tw = p & ((1 << a.lTW) - 1);
+    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    const int n = n0 + tn, tp = ot0 + tt, oh = oh0 + th, ow = ow0 + tw;
+    const bool ok = n < a.N && 2 * tp < To_full && oh < a.Ho && ow < a.Wo;
+    int nv = To_full - 2 * tp;
+    nvalid[nf] = ok ? (nv > 2 ? 2 : nv) : 0;
+    const long e = (long)tn * a.y_nstride + ((long)(2 * tp) * a.yHf + oh) * a.yWf + ow;
+    yvoff[nf] = ok ? (unsigned)(e * 4) + half_rows : OOB;
+  }
+
+  const bool want_stats = a.stats != nullptr;
+  float* red = smem;
+  if (want_stats) __syncthreads();
+
+  auto emit = [&](auto acc_tag, auto fancy_tag) {       // FANCY: see conv_igemm_body
+    constexpr bool ACCUM = decltype(acc_tag)::value;
+    constexpr bool FANCY = decltype(fancy_tag)::value;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);
+        const int ml = rowu + 4 * half;
+        const int co = cout0 + ml;
+        const bool cok = co < a.Cout;
+        const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+        float s = 0.f, ss = 0.f;
+        float bia = 0.f, sc = 1.f, sf = 0.f;
+        if (FANCY) {
+          if (a.bias && cok) bia = a.bias[co];
+          if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const float m0 = acc[mf][nf][0][i], m1 = acc[mf][nf][1][i], m2 = acc[mf][nf][2][i],
+                      m3 = acc[mf][nf][3][i];
+          const float n0_ = acc[mf][nf][4][i], n1 = acc[mf][nf][5][i], n2 = acc[mf][nf][6][i],
+                      n3 = acc[mf][nf][7][i], n4 = acc[mf][nf][8][i];
+          float v[2] = {((m0 + m1) + m2) + ((n0_ + n1) + (n2 + n3)),
+                        ((m1 - m2) - m3) + ((n1 - n2) + fmaf(2.f, n3, n4))};
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const bool fv = f < nvalid[nf];
+            const unsigned vo = (cok && fv) ? yvoff[nf] + (unsigned)f * frame_bytes : OOB;
+            if (ACCUM) v[f] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo, soff, 0));
+            const float u = fv ? v[f] : 0.f;
+            s += u; ss += u * u;
+            if (FANCY) {
+              v[f] = (v[f] + bia) * sc + sf;
+              if (a.relu) v[f] = fmaxf(v[f], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[f]), ry, vo, soff, 0);
+          }
+        }
+        if (want_stats) {
+          s = row16_sum(s);
+          ss = row16_sum(ss);
+          if ((lane & 15) == 0) {
+            const int slot = wn * 2 + (l31 >> 4);
+            red[(slot * BM + ml) * 2 + 0] = s;
+            red[(slot * BM + ml) * 2 + 1] = ss;
+          }
+        }
+      }
+    }
+  };
+  const bool fancy = a.bias || a.ep_scale || a.relu;
+  if (fancy) { if (a.accumulate) emit(std::true_type{}, std::true_type{}); else emit(std::false_type{}, std::true_type{}); }
+  else if (a.accumulate) emit(std::true_type{}, std::false_type{});
+  else emit(std::false_type{}, std::false_type{});
+
+  if (want_stats) {
+    __syncthreads();
+    if (tid < BM) {
+      const int co = cout0 + tid;
+      if (co < a.Cout) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s += red[(k * BM + tid) * 2];
+          ss += red[(k * BM + tid) * 2 + 1];
+        }
+        a.stats[(long)co * a.ntiles + ntile] = s;
+        a.stats[((long)a.Cout + co) * a.ntiles + ntile] = ss;
+      }
+    }
+  }
+}
+
+
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC)
+conv_poly7_kernel(const ConvArgs a) {
+  conv_poly7_body<CC, BM, BNQ, PCH, XV4>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+
+// ------------------------------------------------------------------------------------
 // Spatial (1,3,3) stride-1 pad-1 convolutions through Winograd F(2x2,3x3).
 //
 // A 2x2 block of outputs needs the 4x4 input patch d starting one row/column before it and
@@ -2272,6 +2951,41 @@ __device__ __forceinline__ void pack_element(const PackDesc& d, long e) {
       v = j == 0 ? col[0] : j == 1 ? 0.5f * ((col[0] + col[1]) + col[2])
                           : j == 2 ? 0.5f * ((col[0] - col[1]) + col[2]) : col[2];
     }
+  } else if (d.wino && taps == 9) {
+    // polyphase Winograd operand of the 7-tap stride-2 temporal stem conv (see conv_poly7_body): matrices 0..3 =
+    // F(2,3) of the odd taps (w1, w3, w5), 4..8 = F(2,4) of the even taps (w0, w2, w4, w6)
+    if (rr < Cin && c < Cout) {
+      const float* src = w + c * co_stride + rr * ci_stride + tap_base;
+      const float w0 = src[0], w1 = src[tap_step], w2 = src[2 * tap_step], w3 = src[3 * tap_step],
+                  w4 = src[4 * tap_step], w5 = src[5 * tap_step], w6 = src[6 * tap_step];
+      const float k6 = 1.0f / 6.0f;
+      v = tap == 0 ? w1
+        : tap == 1 ? 0.5f * ((w1 + w3) + w5)
+        : tap == 2 ? 0.5f * ((w1 - w3) + w5)
+        : tap == 3 ? w5
+        : tap == 4 ? 0.5f * w0
+        : tap == 5 ? -0.5f * ((w0 + w2) + (w4 + w6))
+        : tap == 6 ? ((w2 - w0) + (w6 - w4)) * k6
+        : tap == 7 ? ((w0 + 2.f * w2) + (4.f * w4 + 8.f * w6)) * k6
+        : w6;
+    }
+  } else if (d.wino && taps == 6) {
+    // 6 transformed matrices of a 3-tap temporal stencil, F(4,3) (see conv_wino_t4_body); the data
+    // gradient uses the flipped stencil
+    const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
+    if (ok) {
+      const float* src = transpose ? w + rr * co_stride + c * ci_stride
+                                   : w + c * co_stride + rr * ci_stride;
+      float w0 = src[tap_base], w1 = src[tap_base + tap_step], w2 = src[tap_base + 2 * tap_step];
+      if (transpose) { const float t_ = w0; w0 = w2; w2 = t_; }
+      const float k4 = 0.25f, k6 = 1.0f / 6.0f, k12 = 1.0f / 12.0f, k24 = 1.0f / 24.0f;
+      v = tap == 0 ? w0 * k4
+        : tap == 1 ? -((w0 + w1) + w2) * k6
+        : tap == 2 ? -((w0 - w1) + w2) * k6
+        : tap == 3 ? (w0 * k24 + w1 * k12) + w2 * k6
+        : tap == 4 ? (w0 * k24 - w1 * k12) + w2 * k6
+        : w2;
+    }
   } else if (d.wino) {
     // 4 transformed matrices of a 3-tap temporal stencil (taps == 4 here): G0 = w0,
     // G1 = (w0+w1+w2)/2, G2 = (w0-w1+w2)/2, G3 = w2; the data gradient uses the flipped stencil
@@ -2459,6 +3173,47 @@ int launch_wino_t(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot) 
   return wino_t_single<CC, BM, BNP, PCH, XV4, OCC>(a, blocks, lds, stream);
 }
 
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC>
+int launch_wino_t4(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot) {
+  if (p.plane > PCH * 64) return COCLR_EINVAL;
+  a.mtiles = cdiv(a.Cout, BM);
+  a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;
+  a.nchunks = cdiv(a.Cin, CC);
+  const size_t stage = ((size_t)6 * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
+  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
+  const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
+  const size_t lds = lds_main > lds_red ? lds_main : lds_red;
+  if (lds > 160 * 1024) return COCLR_EINVAL;
+  const long blocks = (long)a.mtiles * a.ntiles;
+  if (slot) {
+    slot->args = a; slot->blocks = blocks; slot->lds = lds; slot->pending = true;
+    slot->single = &wino_t4_single<CC, BM, BNQ, PCH, XV4, OCC>;
+    slot->pair = &wino_t4_pair<CC, BM, BNQ, PCH, XV4, OCC>;
+    return 0;
+  }
+  return wino_t4_single<CC, BM, BNQ, PCH, XV4, OCC>(a, blocks, lds, stream);
+}
+
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC>
+int launch_poly7(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
+  if (p.plane > PCH * 64) return COCLR_EINVAL;
+  a.mtiles = cdiv(a.Cout, BM);
+  a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;
+  a.nchunks = cdiv(a.Cin, CC);
+  const size_t stage = ((size_t)9 * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
+  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
+  const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
+  const size_t lds = lds_main > lds_red ? lds_main : lds_red;
+  if (lds > 160 * 1024) return COCLR_EINVAL;
+  const long blocks = (long)a.mtiles * a.ntiles;
+  auto kern = conv_poly7_kernel<CC, BM, BNQ, PCH, XV4, OCC>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
 // efficiency of covering Cout with tiles of BM rows
 inline double cover(int cout, int bm) { return (double)cout / ((double)cdiv(cout, bm) * bm); }
 
@@ -2519,7 +3274,8 @@ int pack_describe(const float* w, float* packed, int cout, int cin, int taps, in
   const int wino = (transpose >> 1) & 1;
   transpose &= 1;
   if (cout <= 0 || cin <= 0 || taps <= 0) return COCLR_EINVAL;
-  if (wino && taps != 4 && taps != 16) return COCLR_EINVAL;
+  if (wino && taps != 4 && taps != 6 && taps != 9 && taps != 16) return COCLR_EINVAL;
+  if (wino && taps == 9 && transpose) return COCLR_EINVAL;      // forward operand only (the data gradient runs in phases)
   if (wino && taps == 16 && rows_total > 0 && cols_total > 0) return COCLR_EINVAL;   // stand-alone only
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
   const bool placed = rows_total > 0 && cols_total > 0;
@@ -2622,6 +3378,16 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
     conv_pick_box(p, c.lbn, 1, 3, 3);
     if (c.lbn == 6) *variant = p->plane <= 256 ? 12 : 13;
     else *variant = c.bm == 128 ? 10 : 11;
+  } else if (kt == 3 && kh == 1 && kw == 1 && d->algo == 2) {
+    // temporal Winograd F(4,3): plan over frame QUADS as a (6,1,1) stencil with stride 4
+    if (!(p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 1 && p->dt == 1 && p->dh == 1 &&
+          p->dw == 1 && p->Ti == p->To && d->ys_t == 0))
+      return COCLR_EINVAL;
+    p->To = (p->To + 3) / 4;
+    p->st = 4;
+    conv_pick_box(p, 6, 6, 1, 1);
+    if (p->plane > 384) return COCLR_EINVAL;
+    *variant = 51;
   } else if (kt == 3 && kh == 1 && kw == 1 && d->algo == 1) {
     // temporal Winograd F(2,3): plan over frame PAIRS as a (4,1,1) stencil with stride 2
     if (!(p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 1 && p->dt == 1 && p->dh == 1 &&
@@ -2647,6 +3413,17 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
       *variant = 31;     // persistent stem kernel: one statistics partial per workgroup
       if (p->ntiles > kStemGrid) p->ntiles = kStemGrid;
     }
+  } else if (kt == 7 && kh == 1 && kw == 1 && d->algo == 1) {
+    // polyphase Winograd form of the stride-2 temporal stem conv: plan over output PAIRS as a (9,1,1)
+    // stencil with stride 4
+    if (!(p->st == 2 && p->sh == 1 && p->sw == 1 && p->pt == 3 && p->dt == 1 && p->dh == 1 && p->dw == 1 &&
+          p->Ti == 2 * p->To && d->ys_t == 0))
+      return COCLR_EINVAL;
+    p->To = (p->To + 1) / 2;
+    p->st = 4;
+    conv_pick_box(p, 6, 9, 1, 1);
+    if (p->plane > 384) return COCLR_EINVAL;
+    *variant = 41;
   } else if (kt == 7 && kh == 1 && kw == 1) {
     conv_pick_box(p, 7, 7, 1, 1);
     *variant = 40;
@@ -2672,13 +3449,13 @@ extern "C" int coclr_conv3d_bwd_sums_ok(const coclr_conv_desc* d, int* ok) {
   int v;
   int rc = plan_forward(d, &p, &v);
   if (rc) return rc;
-  *ok = (v != 60 && v != 31) ? 1 : 0;
+  *ok = (v != 60 && v != 31 && v != 51 && v != 41) ? 1 : 0;
   return 0;
 }
 
 namespace {
 
-inline bool bwd_sums_variant(int variant) { return variant != 60 && variant != 31; }
+inline bool bwd_sums_variant(int variant) { return variant != 60 && variant != 31 && variant != 51 && variant != 41; }
 
 // The launch behind coclr_conv3d_fwd.  With `slot`, variants that have a pair kernel fill it instead of
 // launching (see PairSlot).
@@ -2797,6 +3574,18 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
       if (xv4) return launch_wino_t<8, 64, 64, 4, true, 4>(a, p, stream, slot);
       return launch_wino_t<16, 64, 64, 4, false>(a, p, stream);
     }
+    case 51: {
+      // a.To = frame quads; the kernel finds the frame count in yst and the plane pitch in yHf/yWf
+      a.yst = d->To; a.yHf = p.Ho; a.yWf = p.Wo;
+      a.y_cstride = d->To * p.Ho * p.Wo;
+      a.st = 1;
+      const bool xv4 = p.Hi == 1 && p.WH == 1 && p.lTW >= 2 && (p.Wi % 4) == 0 &&
+                       (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 &&
+                       (p.plane % 4) == 0;
+      if (n_index) return COCLR_EINVAL;
+      if (xv4) return launch_wino_t4<8, 64, 64, 6, true, 3>(a, p, stream, slot);
+      return launch_wino_t4<8, 64, 64, 6, false, 3>(a, p, stream);
+    }
     case 60: {
       // a.Ho/Wo = 2x2 blocks; the destination keeps its full row pitch
       if (n_index || ((uintptr_t)y % 8) != 0 || (a.y_nstride % 2) != 0) return COCLR_EINVAL;
@@ -2845,6 +3634,18 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
     }
     case 30: return launch_variant<1, 7, 7, 4, 64, 128, 20>(a, p, stream);
     case 31: return launch_stem<7, 7, 3, 20>(a, p, stream);
+    case 41: {
+      // a.To = output pairs; the kernel finds the frame count in yst and the plane pitch in yHf/yWf
+      a.yst = d->To; a.yHf = p.Ho; a.yWf = p.Wo;
+      a.y_cstride = d->To * p.Ho * p.Wo;
+      a.st = 1; a.pt = 3;
+      const bool xv4p = p.Hi == 1 && p.WH == 1 && p.lTW >= 2 && (p.Wi % 4) == 0 &&
+                        (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 &&
+                        (p.plane % 4) == 0;
+      if (n_index) return COCLR_EINVAL;
+      if (xv4p) return launch_poly7<8, 64, 64, 6, true, 2>(a, p, stream);
+      return launch_poly7<8, 64, 64, 6, false, 2>(a, p, stream);
+    }
     case 40: return xv4 ? launch_variant<7, 1, 1, 4, 64, 128, 8, true>(a, p, stream)
                         : launch_variant<7, 1, 1, 8, 64, 128, 8>(a, p, stream);
   }

@@ -1077,7 +1077,7 @@ int pick_v2(const coclr_conv_desc* d, WPlan* w) {
   if (d->Cin < 8) return 0;
   ConvPlan& p = w->p2;
   conv_normalise(d, &p);
-  if (id == 2 && d->algo == 1 && d->st == 1 && d->pt == 1 && d->Ti == d->To && d->Cin >= 48 &&
+  if (id == 2 && d->algo >= 1 && d->st == 1 && d->pt == 1 && d->Ti == d->To && d->Cin >= 48 &&
       d->Cout >= 48) {
     // Winograd F(2,3) along T (the layer's forward / data gradient use it: desc.algo = 1): plan the
     // (4,1,1) / stride-2 view over frame PAIRS, 32 pairs per box

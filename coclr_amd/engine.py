@@ -551,7 +551,6 @@ class Run:
         itself.  The last
         node of the backward pass (stage 1) joins as before, which also orders everything in front of the
         optimiser.  What the side kernels read stays referenced until then."""
-        DEFERRED[0] += 1
         keep = _PENDING_SIDE.setdefault(self.device, [])
         keep.extend(self._side_keep)
         for _, ts in self._side_windows:
@@ -566,6 +565,7 @@ class Run:
         dev, keys = self.device, tuple(self.param_grads)
 
         def publish(dev=dev, keys=keys):
+            DEFERRED[0] += 1
             ev = torch.cuda.Event()
             ev.record(_SIDE[dev])
             for k in keys:
@@ -607,10 +607,11 @@ class Run:
         algo=1 the Winograd-domain matrices of a (3,1,1) or (1,3,3) stencil."""
         cout, cin, kt, kh, kw = w.shape
         if algo >= 1:
-            # (3,1,1): 4 matrices of F(2,3); (1,3,3): 16 matrices of F(2x2,3x3)
-            vt = 4 if kt == 3 else 16
+            # (3,1,1): 4 matrices of F(2,3) (algo 1) or 6 of F(4,3) (algo 2); (1,3,3): 16 matrices of F(2x2,3x3)
+            # (7,1,1)/2: the 4 + 5 polyphase matrices of the temporal stem conv
+            vt = (6 if algo == 2 else 4) if kt == 3 else (9 if kt == 7 else 16)
             n = ops.conv_packed_size(cin, cout, vt, transpose)
-            packed = self._packed_buffer(w, ("wino", bool(transpose)), n, False)
+            packed = self._packed_buffer(w, ("wino", bool(transpose), vt), n, False)
             self._relayout(w, packed, (cout, cin, vt, cin * kt * kh * kw, kt * kh * kw, 0,
                                        int(bool(transpose)) | 2, 1), {})
             return packed

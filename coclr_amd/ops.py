@@ -83,9 +83,13 @@ def _chk5(t, name):
 
 WINOGRAD = os.environ.get("COCLR_WINOGRAD", "1") != "0"
 WINOGRAD_HW = os.environ.get("COCLR_WINOGRAD_HW", "1") != "0"
+# (3,1,1) layers through F(4,3) (algo = 2: six contractions per QUAD of output frames, 2x fewer MFMAs than the
+# direct form) instead of F(2,3) (algo = 1: four per pair, 1.5x fewer); "0" keeps F(2,3)
+WINOGRAD_T4 = os.environ.get("COCLR_WINO_T4", "1") != "0"
+WINOGRAD_POLY7 = os.environ.get("COCLR_WINO_POLY7", "1") != "0"
 
 
-def winograd_ok(cin, k, s, p, d, lattice, odim=None):
+def winograd_ok(cin, k, s, p, d, lattice, odim=None, idim=None):
     """Can this convolution run through the Winograd kernels (algo = 1)?  Stride-1 'same'
     convolutions of S3D's separable units (backbone/s3dg.py:39-42):
       * (3,1,1), pad (1,0,0): F(2,3) along T -- 4 channel contractions per pair of output frames
@@ -93,9 +97,15 @@ def winograd_ok(cin, k, s, p, d, lattice, odim=None):
       * (1,3,3), pad (0,1,1), even H and W >= 4: F(2x2,3x3) -- 16 contractions per 2x2 output block
         instead of 36.
     Narrow layers stay direct (the kernels stage 8-16 channels at a time)."""
+    k, p = tuple(k), tuple(p)
+    if k == (7, 1, 1):
+        # the stride-2 temporal stem conv in polyphase form (F(2,3) on the odd taps + F(2,4) on the even ones:
+        # 9 contractions per pair of output frames instead of 14); forward only, even frame counts
+        return (WINOGRAD and WINOGRAD_POLY7 and tuple(s) == (2, 1, 1) and p == (3, 0, 0) and
+                tuple(d) == (1, 1, 1) and lattice is None and cin >= 16 and odim is not None and
+                idim is not None and idim[0] == 2 * odim[0] and odim[0] >= 8)     # >= 4 output pairs per box
     if not (WINOGRAD and tuple(s) == (1, 1, 1) and tuple(d) == (1, 1, 1) and lattice is None):
         return False
-    k, p = tuple(k), tuple(p)
     if k == (3, 1, 1):
         return p == (1, 0, 0) and cin >= 16
     if k == (1, 3, 3):
@@ -104,13 +114,25 @@ def winograd_ok(cin, k, s, p, d, lattice, odim=None):
     return False
 
 
-def winograd_pays(cin, k, s, p, odim):
+def winograd_pays(cin, k, s, p, odim, idim=None):
     """Policy of conv_geom(): use Winograd where it is measurably faster.  The F(2x2,3x3) kernel
     holds one workgroup per CU; on 8x8 maps it only ties the direct kernel and on 4x4 maps it
     loses (profiles/r01_g_layers.txt), so the spatial form is kept for maps of 16x16 and up."""
-    if not winograd_ok(cin, k, s, p, (1, 1, 1), None, odim):
+    if not winograd_ok(cin, k, s, p, (1, 1, 1), None, odim, idim):
         return False
+    if tuple(k) == (7, 1, 1):
+        # measured at the benchmark shape only (32 -> 16 frames: 1.28 -> 1.09 ms, profiles/r06_poly7_ab.txt);
+        # shorter clips keep the direct kernel
+        return odim[0] >= 16
     return tuple(k) != (1, 3, 3) or (odim[1] >= 16 and odim[2] >= 16)
+
+
+def winograd_t4_pays(odim):
+    """F(4,3) instead of F(2,3) for a (3,1,1) layer?  Measured per layer at B=32 (profiles/r06_wino_t4_layers.txt):
+    16 frames (Conv_2c.conv2 0.754 -> 0.598 ms forward, Mixed_3c.b1.conv2 0.185 -> 0.145) yes; 8 frames (Mixed_4f
+    0.080 -> 0.083) and 4 frames (Mixed_5c 0.050 -> 0.068: one quad per position, a third of the window is padding,
+    three workgroups per CU instead of four) no."""
+    return WINOGRAD_T4 and odim[0] >= 16
 
 
 class ConvGeom:
@@ -137,11 +159,14 @@ class ConvGeom:
             tuple(lattice[2])
         # algo 1 = Winograd (see winograd_ok); the packed operand differs
         self.algo = int(algo)
-        if self.algo not in (0, 1):
+        if self.algo not in (0, 1, 2):
             raise ValueError("coclr_amd: unknown convolution algorithm %d" % self.algo)
+        if self.algo == 2 and self.k != (3, 1, 1):
+            raise ValueError("coclr_amd: algorithm 2 is F(4,3) of a (3,1,1) stencil")
         if self.algo >= 1 and not winograd_ok(self.Cin, self.k, self.s, self.p, self.d, lattice,
-                                              self.odim):
-            raise ValueError("coclr_amd: Winograd needs a (3,1,1) or (1,3,3) stride-1 'same' stencil")
+                                              self.odim, self.idim):
+            raise ValueError("coclr_amd: Winograd needs a (3,1,1) or (1,3,3) stride-1 'same' stencil, or the "
+                             "(7,1,1) stride-2 pad-3 temporal stem conv on an even frame count")
         self.desc = ConvDesc(self.N, self.Cin, self.Cout, *self.idim, *self.odim, *self.k,
                              *self.s, *self.p, *self.d, 0, 0, *lat, 0, self.algo)
         self.desc_bw = None
@@ -244,8 +269,9 @@ def conv_geom(N, Cin, Cout, idim, k, s, p):
         if len(_GEOMS) > 8192:
             _GEOMS.clear()
         g = ConvGeom(N, Cin, Cout, idim, k, s, p)
-        if winograd_pays(Cin, k, s, p, g.odim):
-            g = ConvGeom(N, Cin, Cout, idim, k, s, p, algo=1)
+        if winograd_pays(Cin, k, s, p, g.odim, g.idim):
+            g = ConvGeom(N, Cin, Cout, idim, k, s, p,
+                         algo=2 if (tuple(k) == (3, 1, 1) and winograd_t4_pays(g.odim)) else 1)
         _GEOMS[key] = g
     return g
 

@@ -57,7 +57,9 @@ typedef struct coclr_conv_desc {
                               operand made by coclr_conv_pack_weights(transpose | 2):
                               (3,1,1) stencil, stride 1, pad (1,0,0): F(2,3) along T, taps = 4;
                               (1,3,3) stencil, stride 1, pad (0,1,1), even Ho/Wo >= 4, dense
-                              destination, no n_index: F(2x2,3x3), taps = 16 */
+                              destination, no n_index: F(2x2,3x3), taps = 16;
+                              2: (3,1,1) stencil, stride 1, pad (1,0,0), no n_index: F(4,3) along T,
+                              taps = 6 (six contractions per quad of output frames) */
 } coclr_conv_desc;
 
 /* Number of fp32 elements of the packed-weight buffer for one conv. */
@@ -67,7 +69,8 @@ int coclr_conv_packed_size(int cin, int cout, int taps, int transpose, int64_t* 
  * channels R to x32, produced channels C to x128).
  * transpose=0: operand of the forward conv (R = Cin, C = Cout); transpose=1: operand of
  * the data gradient (R = Cout, C = Cin, stencil flipped); transpose | 2: Winograd operand
- * (coclr_conv_desc.algo = 1) -- taps = 4: the four F(2,3) matrices of a 3-tap temporal stencil,
+ * (coclr_conv_desc.algo >= 1) -- taps = 4: the four F(2,3) matrices of a 3-tap temporal stencil,
+ * taps = 6: its six F(4,3) matrices (algo = 2),
  * taps = 16: the sixteen F(2x2,3x3) matrices U = G g G^T of a 9-tap spatial stencil, laid out
  * [R'][C'][16] (stand-alone operands only).  co/ci strides, tap_base and
  * tap_step address a sub-stencil: source tap of packed tap t is tap_base + t*tap_step

@@ -665,11 +665,13 @@ WINO_CASES = [(2, 192, 192, (8, 8, 8)), (3, 208, 208, (4, 8, 8)), (2, 48, 48, (2
               (2, 128, 128, (1, 4, 4)), (3, 96, 80, (16, 16, 16)), (5, 70, 130, (7, 3, 5))]
 
 
+@pytest.mark.parametrize("algo", [1, 2], ids=["F23", "F43"])
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "%d_%d_%d_%s" % c)
-def test_conv_temporal_winograd(case):
-    """(3,1,1) stride-1 pad-1 convolutions through Winograd F(2,3) along T (algo = 1): forward
-    with BatchNorm partial sums, accumulate form, and the data gradient -- odd frame counts,
-    ragged channel counts, a single frame."""
+def test_conv_temporal_winograd(case, algo):
+    """(3,1,1) stride-1 pad-1 convolutions through Winograd along T -- F(2,3) over frame pairs (algo = 1) and
+    F(4,3) over frame quads (algo = 2, what conv_geom() picks from four frames up): forward with BatchNorm
+    partial sums, accumulate form, the inference epilogue (affine + ReLU: CoCLR's frozen sampler) and the data
+    gradient -- frame counts that are not multiples of the group, ragged channel counts, a single frame."""
     from coclr_amd import ops, engine
     N, Cin, Cout, dims = case
     k, s, p = (3, 1, 1), (1, 1, 1), (1, 0, 0)
@@ -679,22 +681,28 @@ def test_conv_temporal_winograd(case):
     ref = F.conv3d(x, w, None, s, p)
     dy = torch.randn_like(ref)
     ref.backward(dy)
-    g = ops.conv_geom(N, Cin, Cout, dims, k, s, p)
-    assert g.algo == 1 and g.dgrad().algo == 1
+    picked = ops.conv_geom(N, Cin, Cout, dims, k, s, p)
+    assert picked.algo == (2 if ops.winograd_t4_pays(dims) else 1)
+    g = ops.ConvGeom(N, Cin, Cout, dims, k, s, p, algo=algo)
+    assert g.dgrad().algo == algo
     run = engine.Run(torch.device("cuda"), save=False)
     wd, xd, dyd = dev(w.detach()), dev(x.detach()), dev(dy)
     y = torch.full((N, Cout, *g.odim), float("nan"), device="cuda")
     stats = torch.empty(2 * Cout * g.ntiles(), device="cuda")
-    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, stats=stats)
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=algo), y, stats=stats)
     close(y, ref, what="winograd fwd")
     st = stats.view(2, Cout, -1).double().sum(-1).cpu()
     close(st[0], ref.double().sum((0, 2, 3, 4)), rtol=1e-3, what="stats sum")
     close(st[1], (ref.double() ** 2).sum((0, 2, 3, 4)), what="stats sumsq")
-    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, accumulate=True)
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=algo), y, accumulate=True)
     close(y, 2 * ref, what="winograd accumulate")
+    sc, sf = torch.rand(Cout) + 0.5, torch.randn(Cout)
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=algo), y, ep_scale=dev(sc), ep_shift=dev(sf), relu=True)
+    close(y, torch.relu(ref.detach() * sc.view(1, -1, 1, 1, 1) + sf.view(1, -1, 1, 1, 1)),
+          what="winograd affine+relu epilogue")
     dx = torch.full((N, Cin, *dims), float("nan"), device="cuda")
     dg = g.dgrad()
-    ops.conv_fwd(dg, dyd, run.pack(wd, True, algo=1), dx)
+    ops.conv_fwd(dg, dyd, run.pack(wd, True, algo=algo), dx)
     close(dx, x.grad, what="winograd dgrad")
     # weight gradient: with desc.algo = 1 the wide layers (>= 48 channels both ways) take the
     # Winograd F(2,3) form (four MFMAs per frame pair instead of six), the others the direct one
@@ -709,6 +717,59 @@ def test_conv_temporal_winograd(case):
     wide[:, 3:3 + Cout] = dyd
     ops.conv_wgrad(g, xd, wide[:, 3:3 + Cout], dw, ws, Cin * 3, 3, 0)
     close(dw, w.grad, what="winograd wgrad from a dY slice")
+
+
+POLY7_CASES = [(2, 64, 64, (32, 16, 16)), (3, 64, 64, (16, 8, 8)), (2, 48, 72, (18, 5, 7)), (5, 16, 130, (16, 4, 4)),
+               (2, 96, 64, (20, 12, 12)), (32, 64, 64, (16, 8, 8))]
+
+
+@pytest.mark.parametrize("case", POLY7_CASES, ids=lambda c: "%d_%d_%d_%s" % c)
+def test_conv_temporal_stem_polyphase_winograd(case):
+    """The (7,1,1) / stride (2,1,1) / pad (3,0,0) temporal stem conv (backbone/s3dg.py:41,145) in polyphase
+    Winograd form (algo = 1 on that stencil: F(2,3) on the odd taps + F(2,4) on the even ones, nine channel
+    contractions per pair of output frames instead of fourteen) against F.conv3d and against the direct kernel:
+    forward with BatchNorm partial sums, accumulate form, inference epilogue; odd output frame counts, ragged
+    channels.  The data gradient of this conv runs in phases (ConvGeom.dgrad_phases), not here."""
+    from coclr_amd import ops, engine
+    N, Cin, Cout, dims = case
+    k, s, p = (7, 1, 1), (2, 1, 1), (3, 0, 0)
+    torch.manual_seed(16)
+    x = torch.randn(N, Cin, *dims)
+    w = torch.randn(Cout, Cin, *k) * 0.05
+    ref = F.conv3d(x, w, None, s, p)
+    picked = ops.conv_geom(N, Cin, Cout, dims, k, s, p)
+    assert picked.algo == (1 if (ops.WINOGRAD_POLY7 and dims[0] >= 32) else 0) and picked.dgrad().algo == 0
+    g = ops.ConvGeom(N, Cin, Cout, dims, k, s, p, algo=1)
+    g0 = ops.ConvGeom(N, Cin, Cout, dims, k, s, p, algo=0)
+    with pytest.raises(ValueError):
+        ops.ConvGeom(N, Cin, Cout, (dims[0] + 1,) + dims[1:], k, s, p, algo=1)        # odd frame count
+    with pytest.raises(ValueError):
+        ops.ConvGeom(N, Cin, Cout, (8,) + dims[1:], k, s, p, algo=1)                  # fewer than four output pairs
+    assert ops.conv_geom(N, Cin, Cout, (8,) + dims[1:], k, s, p).algo == 0
+    run = engine.Run(torch.device("cuda"), save=False)
+    wd, xd = dev(w), dev(x)
+    y = torch.full((N, Cout, *g.odim), float("nan"), device="cuda")
+    stats = torch.empty(2 * Cout * g.ntiles(), device="cuda")
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, stats=stats)
+    close(y, ref, what="polyphase fwd")
+    y0 = torch.empty_like(y)
+    ops.conv_fwd(g0, xd, run.pack(wd, False), y0)
+    close(y, y0, rtol=2e-5, what="polyphase vs direct kernel")
+    st = stats.view(2, Cout, -1).double().sum(-1).cpu()
+    close(st[0], ref.double().sum((0, 2, 3, 4)), rtol=1e-3, what="stats sum")
+    close(st[1], (ref.double() ** 2).sum((0, 2, 3, 4)), what="stats sumsq")
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, accumulate=True)
+    close(y, 2 * ref, what="polyphase accumulate")
+    sc, sf = torch.rand(Cout) + 0.5, torch.randn(Cout)
+    ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, ep_scale=dev(sc), ep_shift=dev(sf), relu=True)
+    close(y, torch.relu(ref * sc.view(1, -1, 1, 1, 1) + sf.view(1, -1, 1, 1, 1)), what="polyphase affine+relu epilogue")
+    # into a channel slice of a wider tensor, from a channel slice of a wider input
+    wide = torch.zeros(N, Cout + 8, *g.odim, device="cuda")
+    xw = torch.zeros(N, Cin + 4, *dims, device="cuda")
+    xw[:, 2:2 + Cin] = xd
+    ops.conv_fwd(g, xw[:, 2:2 + Cin], run.pack(wd, False, algo=1), wide[:, 8:])
+    close(wide[:, 8:], ref, what="polyphase between channel slices")
+    assert wide[:, :8].abs().max().item() == 0
 
 
 WINO_HW_CASES = [(2, 64, 192, (2, 32, 32)), (2, 192, 208, (4, 16, 16)), (3, 48, 96, (3, 8, 8)),

@@ -12,10 +12,12 @@ pytestmark = pytest.mark.gpu
 B = 32
 
 
-def _conv_case(run, cin, cout, k, p, idim, seed, dgrad=False, accumulate=False, stats=True):
+def _conv_case(run, cin, cout, k, p, idim, seed, dgrad=False, accumulate=False, stats=True, algo=None):
     from coclr_amd import ops
     g = torch.Generator(device="cuda").manual_seed(seed)
     geom = ops.conv_geom(B, cin, cout, idim, k, (1, 1, 1), p)
+    if algo is not None and geom.algo != algo:
+        geom = ops.ConvGeom(B, cin, cout, idim, k, (1, 1, 1), p, algo=algo)
     w = torch.randn(cout, cin, *k, device="cuda", generator=g) * 0.05
     if dgrad:
         dg = geom.dgrad()
@@ -264,6 +266,12 @@ def test_data_gradient_forms_batchnorm_backward_sums(name, spec, relu):
     run = engine.Run(torch.device("cuda"), save=False)
     case = _conv_case(run, *spec, seed=31, dgrad=True)
     geom = case["geom"]
+    if geom.algo == 2:
+        # the F(4,3) kernel (16-frame temporal layers) does not form the sums -- the engine asks
+        # (geom.bwd_sums_ok()) and keeps the reduction pass there; the F(2,3) form of the same layer does
+        assert not geom.bwd_sums_ok()
+        case = _conv_case(run, *spec, seed=31, dgrad=True, algo=1)
+        geom = case["geom"]
     assert geom.bwd_sums_ok()
     plain, _ = _run_single(case)
     bb = _bwd_bn_operands(tuple(plain.shape), 32, relu)
@@ -394,6 +402,10 @@ def test_engine_with_the_sums_epilogue_matches_the_reduction_pass(monkeypatch):
         return real(units)
 
     monkeypatch.setattr(ops, "bn_act_backward_multi", spy)
+    # Conv_2c.conv2's data gradient in its F(2,3) form: the F(4,3) kernel the 16-frame layers take by default does
+    # not form the sums (the engine then keeps the reduction pass for Conv_2c.bn1)
+    monkeypatch.setattr(ops, "WINOGRAD_T4", False)
+    ops._GEOMS.clear()
     g = torch.Generator(device="cuda").manual_seed(9)
     x = torch.randn(16, 3, 32, 64, 64, device="cuda", generator=g)     # Conv_2c: 65536 values per channel
     grads = []
@@ -411,3 +423,4 @@ def test_engine_with_the_sums_epilogue_matches_the_reduction_pass(monkeypatch):
     assert torch.equal(oa, ob)
     for k in ga:
         assert (ga[k] - gb[k]).abs().max() <= 1e-5 * ga[k].abs().max() + 1e-12, k
+    ops._GEOMS.clear()        # geometries cached with the F(2,3) choice must not leak into later tests
