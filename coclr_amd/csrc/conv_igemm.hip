@@ -78,6 +78,7 @@ struct ConvArgs {
   int mtiles, ntiles, nchunks;
   int relu, accumulate;
   int xcd;                // remap workgroup ids so that an XCD owns contiguous tiles
+  int To_full;            // F(4,3) / F(2,4) temporal kernels: output frames of the launch (a.To counts groups)
 };
 
 // sum over each 16-lane row (result in every lane of the row)
@@ -1157,8 +1158,10 @@ __device__ __forceinline__ void conv_wino_t4_body(const ConvArgs& a, int bid, co
   unsigned yvoff[NF];
   int nvalid[NF];                 // valid frames of the quad (0 = position outside the tensor)
   const unsigned half_rows = (unsigned)half * 4u * (unsigned)a.y_cstride * 4u;
-  const unsigned frame_bytes = (unsigned)(a.yHf * a.yWf) * 4u;
-  const int To_full = a.yst;     // launcher passes the un-grouped frame count here
+  // destination lattice along T (one phase of a strided data gradient): output frame o lands on frame
+  // o * yst + yot of the destination tensor; dense: yst = 1, yot = 0
+  const unsigned frame_bytes = (unsigned)(a.yHf * a.yWf) * 4u * (unsigned)a.yst;
+  const int To_full = a.To_full;
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
     const int p = wn * (BNQ / WN) + nf * 32 + l31;
@@ -1170,7 +1173,7 @@ __device__ __forceinline__ void conv_wino_t4_body(const ConvArgs& a, int bid, co
     const bool ok = n < a.N && 4 * tp < To_full && oh < a.Ho && ow < a.Wo;
     int nv = To_full - 4 * tp;
     nvalid[nf] = ok ? (nv > 4 ? 4 : nv) : 0;
-    const long e = (long)tn * a.y_nstride + ((long)(4 * tp) * a.yHf + oh) * a.yWf + ow;
+    const long e = (long)tn * a.y_nstride + ((long)(4 * tp * a.yst + a.yot) * a.yHf + oh) * a.yWf + ow;
     yvoff[nf] = ok ? (unsigned)(e * 4) + half_rows : OOB;
   }
 
@@ -1287,6 +1290,319 @@ int wino_t4_pair(const ConvArgs& a0, const ConvArgs& a1, long b0, long b1, size_
 
 template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC = 1>
 int launch_wino_t4(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot = nullptr);
+
+// ------------------------------------------------------------------------------------
+// A 4-tap temporal stencil (4,1,1) / stride 1 / pad (1,0,0) through Winograd F(2,4) (coclr_conv_desc.algo = 2
+// on that stencil): the odd phase of the strided stem conv's data gradient (ConvGeom.dgrad_phases).  A PAIR of
+// output frames (2p, 2p+1) needs input frames o0..o4 = 2p-1 .. 2p+3 and FIVE channel contractions instead of
+// eight (points 0, 1, -1, 2, inf; the same transform as the even-tap half of conv_poly7_body):
+//     O = (2(o0-o2)+(o3-o1), -2o1-o2+o3, 2o1-3o2+o3, o3-o1, 2(o1-o3)+(o4-o2))
+//     U = (b0/2, -(b0+b1+b2+b3)/2, (-b0+b1-b2+b3)/6, (b0+2b1+4b2+8b3)/6, b3)
+//     y[2p] = n0+n1+n2+n3        y[2p+1] = n1-n2+2n3+n4
+// Writes through the destination lattice along T like conv_wino_t4_body.
+template <int CC, int BM, int BNQ, int PCH, bool XV4>
+__device__ __forceinline__ void conv_wino_t24_body(const ConvArgs& a, int bid, const int nblocks) {
+  constexpr int TAPS = 5;
+  constexpr int WM = 2, WN = 2;
+  constexpr int MF = BM / (WM * 32), NF = BNQ / (WN * 32);
+  constexpr int RPP = 256 / BM;
+  constexpr int WPIECES = TAPS * CC / RPP;
+  static_assert(CC % RPP == 0 && CC % 4 == 0, "chunk shape");
+  constexpr int W_FLOATS = TAPS * CC * BM;
+
+  extern __shared__ __align__(16) float smem[];
+  const int planeS = a.planeS;
+  const int stage_floats = W_FLOATS + CC * planeS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  if (a.xcd) {                        // XCD-aware tile ids (see conv_igemm_body)
+    const int per = nblocks >> 3;
+    if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int mt = bid % a.mtiles;
+  const int ntile = bid / a.mtiles;
+  int r = ntile;
+  const int bw_ = r % a.nbw; r /= a.nbw;
+  const int bh_ = r % a.nbh; r /= a.nbh;
+  const int bt_ = r % a.nbt; r /= a.nbt;
+  const int n0 = r << a.lTN;
+  const int ow0 = bw_ << a.lTW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;   // ot0: PAIR index
+  const int cout0 = mt * BM;
+  const int vt0 = ot0 * 2 - 1, vh0 = oh0, vw0 = ow0;                      // window origin
+  const int plane = a.plane;
+
+  const float* xbase = a.x + (long)n0 * a.x_nstride;
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, BUF_RANGE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, BUF_RANGE, 0x00020000);
+  float* ybase = a.y + (long)n0 * a.y_nstride;
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, BUF_RANGE, 0x00020000);
+
+  unsigned goff[XV4 ? 1 : PCH];
+  if (!XV4) {
+    const int hw = a.WH * a.WW;
+#pragma unroll
+    for (int j = 0; j < PCH; ++j) {
+      const int e = j * 64 + lane;
+      unsigned off = OOB;
+      if (e < plane) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_hw); q -= wt * hw;
+        const int wh = fdiv(q, a.inv_ww);
+        const int ww = q - wh * a.WW;
+        const int n = n0 + wn_;
+        const int it = vt0 + wt, ih = vh0 + wh, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && ih < a.Hi && iw < a.Wi)
+          off = (unsigned)(((long)wn_ * a.x_nstride + ((long)it * a.Hi + ih) * a.Wi + iw) * 4);
+      }
+      goff[j] = off;
+    }
+  }
+  const unsigned wvoff = (unsigned)((((lane * 4) / BM) * a.CoutP + (lane * 4) % BM) * 4);
+
+  // XV4: 16-byte DMA of the halo-free window, 1 KiB pieces across channel rows (see conv_wino_t_body)
+  constexpr int PV = (CC * PCH * 64 / 256 + 3) / 4;
+  unsigned xvoff[PV];
+  int xvc[PV];
+  if (XV4) {
+#pragma unroll
+    for (int jj = 0; jj < PV; ++jj) {
+      const int flat = (wave + 4 * jj) * 256 + lane * 4;
+      const int c = flat / plane, e = flat - c * plane;
+      unsigned off = OOB;
+      if (c < CC) {
+        const int wn_ = fdiv(e, a.inv_plane1);
+        const int q = e - wn_ * a.plane1;
+        const int wt = fdiv(q, a.inv_ww);              // WH == 1 here
+        const int ww = q - wt * a.WW;
+        const int n = n0 + wn_, it = vt0 + wt, iw = vw0 + ww;
+        if (n < a.N && it >= 0 && it < a.Ti && iw < a.Wi)
+          off = (unsigned)(((long)wn_ * a.x_nstride + (long)it * a.Wi + iw + (long)c * a.x_cstride) * 4);
+      }
+      xvoff[jj] = off;
+      xvc[jj] = c;
+    }
+  }
+
+  // pair position of this lane: window offset of its frame o0 (o1..o4 follow at +WH*WW each)
+  int lanebase[NF];
+  const int fstride = a.WH * a.WW;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BNQ / WN) + nf * 32 + l31;
+    const int tw = p & ((1 << a.lTW) - 1);
+    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    lanebase[nf] = W_FLOATS + tn * a.plane1 + ((tt * 2) * a.WH + th) * a.WW + tw + half * planeS;
+  }
+  const int abase = half * BM + wm * (BM / WM) + l31;
+
+  f32x16 acc[MF][NF][5];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mf][nf][t][i] = 0.f;
+
+  auto stage = [&](int cin0, float* sbase) {
+    for (int p = wave; p < WPIECES; p += 4) {
+      const int row0 = p * RPP;
+      const int tap = row0 / CC, c0 = row0 % CC;
+      const unsigned soff = (unsigned)((((long)tap * a.CinP + cin0 + c0) * a.CoutP + cout0) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sbase + p * 256), 16, wvoff, soff, 0, 0);
+    }
+    float* xs = sbase + W_FLOATS;
+    if (XV4) {
+      const unsigned soff = (unsigned)cin0 * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+      for (int jj = 0; jj < PV; ++jj) {
+        const int j = wave + 4 * jj;
+        if (j * 256 < CC * plane && xvc[jj] < CC) {   // exec-masked: lanes past the image write nothing
+          const unsigned vo = cin0 + xvc[jj] < a.Cin ? xvoff[jj] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + j * 256), 16, vo, soff, 0, 0);
+        }
+      }
+    } else
+#pragma unroll
+    for (int ci = 0; ci < CC / 4; ++ci) {
+      const int c = ci * 4 + wave;
+      const int cin = cin0 + c;
+      if (cin < a.Cin) {
+        const unsigned soff = (unsigned)cin * (unsigned)a.x_cstride * 4u;
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + c * planeS + j * 64), 4,
+                                                     goff[XV4 ? 0 : j], soff, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < PCH; ++j)
+          if (j * 64 < plane) xs[c * planeS + j * 64 + lane] = 0.f;
+      }
+    }
+  };
+
+  const int nchunks = a.nchunks;
+  stage(0, smem);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* cur = smem + (ch & 1) * stage_floats;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (ch + 1 < nchunks) stage((ch + 1) * CC, smem + ((ch + 1) & 1) * stage_floats);
+
+    constexpr int QS = CC / 2;
+    // step q: channel pair (2q, 2q+1); operands of step q+1 are fetched under the MFMAs of q
+    auto fetch = [&](int q, float (&av)[MF][5], float (&dv)[NF][5]) {
+#pragma unroll
+      for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) av[mf][t] = cur[abase + (t * CC + 2 * q) * BM + mf * 32];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dv[nf][k] = cur[lanebase[nf] + k * fstride + 2 * q * planeS];
+    };
+    float av[2][MF][5], dv[2][NF][5];
+    fetch(0, av[0], dv[0]);
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      if (q + 1 < QS) fetch(q + 1, av[(q + 1) & 1], dv[(q + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const float o0 = dv[q & 1][nf][0], o1 = dv[q & 1][nf][1], o2 = dv[q & 1][nf][2],
+                    o3 = dv[q & 1][nf][3], o4 = dv[q & 1][nf][4];
+        const float oa = o3 - o2, o31 = o3 - o1;
+        const float D[5] = {fmaf(2.f, o0 - o2, o31), fmaf(-2.f, o1, oa), fmaf(2.f, o1, fmaf(-2.f, o2, oa)), o31,
+                            fmaf(-2.f, o31, o4 - o2)};
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf)
+            acc[mf][nf][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][mf][t], D[t],
+                                                                  acc[mf][nf][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: two frames per pair position -----------------------------------------------------
+  unsigned yvoff[NF];
+  int nvalid[NF];                 // valid frames of the quad (0 = position outside the tensor)
+  const unsigned half_rows = (unsigned)half * 4u * (unsigned)a.y_cstride * 4u;
+  // destination lattice along T (one phase of a strided data gradient): output frame o lands on frame
+  // o * yst + yot of the destination tensor; dense: yst = 1, yot = 0
+  const unsigned frame_bytes = (unsigned)(a.yHf * a.yWf) * 4u * (unsigned)a.yst;
+  const int To_full = a.To_full;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int p = wn * (BNQ / WN) + nf * 32 + l31;
+    const int tw = p & ((1 << a.lTW) - 1);
+    const int th = (p >> a.lTW) & ((1 << a.lTH) - 1);
+    const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+    const int tn = p >> (a.lTW + a.lTH + a.lTT);
+    const int n = n0 + tn, tp = ot0 + tt, oh = oh0 + th, ow = ow0 + tw;
+    const bool ok = n < a.N && 2 * tp < To_full && oh < a.Ho && ow < a.Wo;
+    int nv = To_full - 2 * tp;
+    nvalid[nf] = ok ? (nv > 2 ? 2 : nv) : 0;
+    const long e = (long)tn * a.y_nstride + ((long)(2 * tp * a.yst + a.yot) * a.yHf + oh) * a.yWf + ow;
+    yvoff[nf] = ok ? (unsigned)(e * 4) + half_rows : OOB;
+  }
+
+  const bool want_stats = a.stats != nullptr;
+  float* red = smem;
+  if (want_stats) __syncthreads();
+
+  auto emit = [&](auto acc_tag, auto fancy_tag) {       // FANCY: see conv_igemm_body
+    constexpr bool ACCUM = decltype(acc_tag)::value;
+    constexpr bool FANCY = decltype(fancy_tag)::value;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rowu = wm * (BM / WM) + mf * 32 + (i & 3) + 8 * (i >> 2);
+        const int ml = rowu + 4 * half;
+        const int co = cout0 + ml;
+        const bool cok = co < a.Cout;
+        const unsigned soff = (unsigned)(cout0 + rowu) * (unsigned)a.y_cstride * 4u;
+        float s = 0.f, ss = 0.f;
+        float bia = 0.f, sc = 1.f, sf = 0.f;
+        if (FANCY) {
+          if (a.bias && cok) bia = a.bias[co];
+          if (a.ep_scale && cok) { sc = a.ep_scale[co]; sf = a.ep_shift[co]; }
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const float n0_ = acc[mf][nf][0][i], n1 = acc[mf][nf][1][i], n2 = acc[mf][nf][2][i],
+                      n3 = acc[mf][nf][3][i], n4 = acc[mf][nf][4][i];
+          float v[2] = {(n0_ + n1) + (n2 + n3), (n1 - n2) + fmaf(2.f, n3, n4)};
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const bool fv = f < nvalid[nf];
+            const unsigned vo = (cok && fv) ? yvoff[nf] + (unsigned)f * frame_bytes : OOB;
+            if (ACCUM) v[f] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, vo, soff, 0));
+            const float u = fv ? v[f] : 0.f;
+            s += u; ss += u * u;
+            if (FANCY) {
+              v[f] = (v[f] + bia) * sc + sf;
+              if (a.relu) v[f] = fmaxf(v[f], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[f]), ry, vo, soff, 0);
+          }
+        }
+        if (want_stats) {
+          s = row16_sum(s);
+          ss = row16_sum(ss);
+          if ((lane & 15) == 0) {
+            const int slot = wn * 2 + (l31 >> 4);
+            red[(slot * BM + ml) * 2 + 0] = s;
+            red[(slot * BM + ml) * 2 + 1] = ss;
+          }
+        }
+      }
+    }
+  };
+  const bool fancy = a.bias || a.ep_scale || a.relu;
+  if (fancy) { if (a.accumulate) emit(std::true_type{}, std::true_type{}); else emit(std::false_type{}, std::true_type{}); }
+  else if (a.accumulate) emit(std::true_type{}, std::false_type{});
+  else emit(std::false_type{}, std::false_type{});
+
+  if (want_stats) {
+    __syncthreads();
+    if (tid < BM) {
+      const int co = cout0 + tid;
+      if (co < a.Cout) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s += red[(k * BM + tid) * 2];
+          ss += red[(k * BM + tid) * 2 + 1];
+        }
+        a.stats[(long)co * a.ntiles + ntile] = s;
+        a.stats[((long)a.Cout + co) * a.ntiles + ntile] = ss;
+      }
+    }
+  }
+}
+
+
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC)
+conv_wino_t24_kernel(const ConvArgs a) {
+  conv_wino_t24_body<CC, BM, BNQ, PCH, XV4>(a, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // ------------------------------------------------------------------------------------
 // The temporal stem conv (7,1,1) / stride 2 / pad 3 (STConv3d's second half in Conv_1a, backbone/s3dg.py:41,145)
@@ -2969,6 +3285,23 @@ __device__ __forceinline__ void pack_element(const PackDesc& d, long e) {
         : tap == 7 ? ((w0 + 2.f * w2) + (4.f * w4 + 8.f * w6)) * k6
         : w6;
     }
+  } else if (d.wino && taps == 5) {
+    // 5 transformed matrices of a 4-tap temporal stencil, F(2,4) (see conv_wino_t24_body); the data gradient
+    // uses the flipped stencil
+    const bool ok = transpose ? (rr < Cout && c < Cin) : (rr < Cin && c < Cout);
+    if (ok) {
+      const float* src = transpose ? w + rr * co_stride + c * ci_stride
+                                   : w + c * co_stride + rr * ci_stride;
+      float b0 = src[tap_base], b1 = src[tap_base + tap_step], b2 = src[tap_base + 2 * tap_step],
+            b3 = src[tap_base + 3 * tap_step];
+      if (transpose) { float t_ = b0; b0 = b3; b3 = t_; t_ = b1; b1 = b2; b2 = t_; }
+      const float k6 = 1.0f / 6.0f;
+      v = tap == 0 ? 0.5f * b0
+        : tap == 1 ? -0.5f * ((b0 + b1) + (b2 + b3))
+        : tap == 2 ? ((b1 - b0) + (b3 - b2)) * k6
+        : tap == 3 ? ((b0 + 2.f * b1) + (4.f * b2 + 8.f * b3)) * k6
+        : b3;
+    }
   } else if (d.wino && taps == 6) {
     // 6 transformed matrices of a 3-tap temporal stencil, F(4,3) (see conv_wino_t4_body); the data
     // gradient uses the flipped stencil
@@ -3195,6 +3528,26 @@ int launch_wino_t4(ConvArgs& a, ConvPlan& p, hipStream_t stream, PairSlot* slot)
 }
 
 template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC>
+int launch_wino_t24(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
+  if (p.plane > PCH * 64) return COCLR_EINVAL;
+  a.mtiles = cdiv(a.Cout, BM);
+  a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;
+  a.nchunks = cdiv(a.Cin, CC);
+  const size_t stage = ((size_t)5 * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
+  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
+  const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
+  const size_t lds = lds_main > lds_red ? lds_main : lds_red;
+  if (lds > 160 * 1024) return COCLR_EINVAL;
+  const long blocks = (long)a.mtiles * a.ntiles;
+  auto kern = conv_wino_t24_kernel<CC, BM, BNQ, PCH, XV4, OCC>;
+  static std::atomic<uint64_t> attr_done{0};
+  COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC>
 int launch_poly7(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   if (p.plane > PCH * 64) return COCLR_EINVAL;
   a.mtiles = cdiv(a.Cout, BM);
@@ -3274,7 +3627,7 @@ int pack_describe(const float* w, float* packed, int cout, int cin, int taps, in
   const int wino = (transpose >> 1) & 1;
   transpose &= 1;
   if (cout <= 0 || cin <= 0 || taps <= 0) return COCLR_EINVAL;
-  if (wino && taps != 4 && taps != 6 && taps != 9 && taps != 16) return COCLR_EINVAL;
+  if (wino && taps != 4 && taps != 5 && taps != 6 && taps != 9 && taps != 16) return COCLR_EINVAL;
   if (wino && taps == 9 && transpose) return COCLR_EINVAL;      // forward operand only (the data gradient runs in phases)
   if (wino && taps == 16 && rows_total > 0 && cols_total > 0) return COCLR_EINVAL;   // stand-alone only
   const int r = transpose ? cout : cin, c = transpose ? cin : cout;
@@ -3381,7 +3734,8 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
   } else if (kt == 3 && kh == 1 && kw == 1 && d->algo == 2) {
     // temporal Winograd F(4,3): plan over frame QUADS as a (6,1,1) stencil with stride 4
     if (!(p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 1 && p->dt == 1 && p->dh == 1 &&
-          p->dw == 1 && p->Ti == p->To && d->ys_t == 0))
+          p->dw == 1 && p->Ti == p->To &&
+          (d->ys_t == 0 || (d->ys_h == 1 && d->ys_w == 1 && d->yo_h == 0 && d->yo_w == 0))))
       return COCLR_EINVAL;
     p->To = (p->To + 3) / 4;
     p->st = 4;
@@ -3402,6 +3756,17 @@ int plan_forward(const coclr_conv_desc* d, ConvPlan* p, int* variant) {
     c = choose_tile(*p, 3, 1, 1, true, true, 256, 256);
     conv_pick_box(p, c.lbn, 3, 1, 1);
     *variant = c.lbn == 6 ? 22 : (c.bm == 128 ? 20 : 21);
+  } else if (kt == 4 && kh == 1 && kw == 1 && d->algo == 2) {
+    // 4-tap temporal stencil through F(2,4): plan over frame PAIRS as a (5,1,1) stencil with stride 2
+    if (!(p->st == 1 && p->sh == 1 && p->sw == 1 && p->pt == 1 && p->dt == 1 && p->dh == 1 &&
+          p->dw == 1 && p->Ti == p->To &&
+          (d->ys_t == 0 || (d->ys_h == 1 && d->ys_w == 1 && d->yo_h == 0 && d->yo_w == 0))))
+      return COCLR_EINVAL;
+    p->To = (p->To + 1) / 2;
+    p->st = 2;
+    conv_pick_box(p, 6, 5, 1, 1);
+    if (p->plane > 256) return COCLR_EINVAL;
+    *variant = 52;
   } else if (kt == 4 && kh == 1 && kw == 1) {
     conv_pick_box(p, 7, 4, 1, 1);
     *variant = 25;
@@ -3449,13 +3814,15 @@ extern "C" int coclr_conv3d_bwd_sums_ok(const coclr_conv_desc* d, int* ok) {
   int v;
   int rc = plan_forward(d, &p, &v);
   if (rc) return rc;
-  *ok = (v != 60 && v != 31 && v != 51 && v != 41) ? 1 : 0;
+  *ok = (v != 60 && v != 31 && v != 51 && v != 52 && v != 41) ? 1 : 0;
   return 0;
 }
 
 namespace {
 
-inline bool bwd_sums_variant(int variant) { return variant != 60 && variant != 31 && variant != 51 && variant != 41; }
+inline bool bwd_sums_variant(int variant) {
+  return variant != 60 && variant != 31 && variant != 51 && variant != 52 && variant != 41;
+}
 
 // The launch behind coclr_conv3d_fwd.  With `slot`, variants that have a pair kernel fill it instead of
 // launching (see PairSlot).
@@ -3508,6 +3875,7 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
   a.inv_ww = 1.0f / (float)p.WW;
   a.ntiles = p.ntiles; a.mtiles = 0; a.planeS = 0; a.nchunks = 0;
   a.relu = relu; a.accumulate = accumulate;
+  a.To_full = 0;
   {
     static const bool xcd_off = getenv("COCLR_XCD_MAP") && atoi(getenv("COCLR_XCD_MAP")) == 0;
     a.xcd = !xcd_off;
@@ -3574,16 +3942,25 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
       if (xv4) return launch_wino_t<8, 64, 64, 4, true, 4>(a, p, stream, slot);
       return launch_wino_t<16, 64, 64, 4, false>(a, p, stream);
     }
-    case 51: {
-      // a.To = frame quads; the kernel finds the frame count in yst and the plane pitch in yHf/yWf
-      a.yst = d->To; a.yHf = p.Ho; a.yWf = p.Wo;
-      a.y_cstride = d->To * p.Ho * p.Wo;
+    case 51:
+    case 52: {
+      // a.To = frame quads (F(4,3)) / pairs (F(2,4)); the kernel finds the frame count in To_full and, when the
+      // destination is dense, the plane pitch in yHf/yWf (a lattice along T keeps what was set above)
+      a.To_full = d->To;
+      if (!lattice) {
+        a.yst = 1; a.yot = 0; a.yHf = p.Ho; a.yWf = p.Wo;
+        a.y_cstride = d->To * p.Ho * p.Wo;
+      }
       a.st = 1;
       const bool xv4 = p.Hi == 1 && p.WH == 1 && p.lTW >= 2 && (p.Wi % 4) == 0 &&
                        (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 &&
                        (p.plane % 4) == 0;
       if (n_index) return COCLR_EINVAL;
-      if (xv4) return launch_wino_t4<8, 64, 64, 6, true, 3>(a, p, stream, slot);
+      if (variant == 52) {
+        if (xv4) return launch_wino_t24<8, 64, 64, 4, true, 3>(a, p, stream);
+        return launch_wino_t24<8, 64, 64, 4, false, 3>(a, p, stream);
+      }
+      if (xv4) return launch_wino_t4<8, 64, 64, 6, true, 3>(a, p, stream, slot && !lattice ? slot : nullptr);
       return launch_wino_t4<8, 64, 64, 6, false, 3>(a, p, stream);
     }
     case 60: {

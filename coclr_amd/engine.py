@@ -606,6 +606,15 @@ class Run:
         one temporal slice of the stencil; (taps, tap_base, tap_step) an arithmetic subset;
         algo=1 the Winograd-domain matrices of a (3,1,1) or (1,3,3) stencil."""
         cout, cin, kt, kh, kw = w.shape
+        if algo >= 1 and taps is not None:
+            # a 3- or 4-tap arithmetic subset of a temporal stencil (one phase of a strided data gradient):
+            # 6 matrices of F(4,3) / 5 of F(2,4)
+            vt = {3: 6, 4: 5}[taps]
+            n = ops.conv_packed_size(cin, cout, vt, transpose)
+            packed = self._packed_buffer(w, ("wino", bool(transpose), vt, tap_base, tap_step), n, False)
+            self._relayout(w, packed, (cout, cin, vt, cin * kt * kh * kw, kt * kh * kw, tap_base,
+                                       int(bool(transpose)) | 2, tap_step), {})
+            return packed
         if algo >= 1:
             # (3,1,1): 4 matrices of F(2,3) (algo 1) or 6 of F(4,3) (algo 2); (1,3,3): 16 matrices of F(2x2,3x3)
             # (7,1,1)/2: the 4 + 5 polyphase matrices of the temporal stem conv
@@ -992,7 +1001,7 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
                     if src is not None and not (len(phases) <= 2 and all(ph[0].bwd_sums_ok() for ph in phases)):
                         src = None
                     for pg, k0, nk, step in phases:
-                        wp = run.pack(w, True, taps=nk, tap_base=k0, tap_step=step)
+                        wp = run.pack(w, True, taps=nk, tap_base=k0, tap_step=step, algo=pg.algo)
                         if src is not None:
                             nt = pg.ntiles()
                             st = torch.empty(2 * pg.Cout * nt, dtype=torch.float32, device=dx.device)

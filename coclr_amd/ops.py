@@ -87,9 +87,10 @@ WINOGRAD_HW = os.environ.get("COCLR_WINOGRAD_HW", "1") != "0"
 # direct form) instead of F(2,3) (algo = 1: four per pair, 1.5x fewer); "0" keeps F(2,3)
 WINOGRAD_T4 = os.environ.get("COCLR_WINO_T4", "1") != "0"
 WINOGRAD_POLY7 = os.environ.get("COCLR_WINO_POLY7", "1") != "0"
+WINOGRAD_PHASES = os.environ.get("COCLR_WINO_PHASES", "1") != "0"
 
 
-def winograd_ok(cin, k, s, p, d, lattice, odim=None, idim=None):
+def winograd_ok(cin, k, s, p, d, lattice, odim=None, idim=None, algo=1):
     """Can this convolution run through the Winograd kernels (algo = 1)?  Stride-1 'same'
     convolutions of S3D's separable units (backbone/s3dg.py:39-42):
       * (3,1,1), pad (1,0,0): F(2,3) along T -- 4 channel contractions per pair of output frames
@@ -104,8 +105,17 @@ def winograd_ok(cin, k, s, p, d, lattice, odim=None, idim=None):
         return (WINOGRAD and WINOGRAD_POLY7 and tuple(s) == (2, 1, 1) and p == (3, 0, 0) and
                 tuple(d) == (1, 1, 1) and lattice is None and cin >= 16 and odim is not None and
                 idim is not None and idim[0] == 2 * odim[0] and odim[0] >= 8)     # >= 4 output pairs per box
-    if not (WINOGRAD and tuple(s) == (1, 1, 1) and tuple(d) == (1, 1, 1) and lattice is None):
+    if lattice is not None:
+        # a destination lattice along T only, and only in the F(4,3) / F(2,4) kernels (algo = 2): the even / odd
+        # phase of the strided temporal stem conv's data gradient (ConvGeom.dgrad_phases)
+        ys, yo = tuple(lattice[0]), tuple(lattice[1])
+        if not (algo == 2 and ys[1:] == (1, 1) and yo[1:] == (0, 0)):
+            return False
+    if not (WINOGRAD and tuple(s) == (1, 1, 1) and tuple(d) == (1, 1, 1)):
         return False
+    if k == (4, 1, 1):
+        return algo == 2 and p == (1, 0, 0) and cin >= 16 and odim is not None and idim is not None and \
+            odim[0] == idim[0]
     if k == (3, 1, 1):
         return p == (1, 0, 0) and cin >= 16
     if k == (1, 3, 3):
@@ -161,10 +171,10 @@ class ConvGeom:
         self.algo = int(algo)
         if self.algo not in (0, 1, 2):
             raise ValueError("coclr_amd: unknown convolution algorithm %d" % self.algo)
-        if self.algo == 2 and self.k != (3, 1, 1):
-            raise ValueError("coclr_amd: algorithm 2 is F(4,3) of a (3,1,1) stencil")
+        if self.algo == 2 and self.k not in ((3, 1, 1), (4, 1, 1)):
+            raise ValueError("coclr_amd: algorithm 2 is F(4,3) of a (3,1,1) stencil or F(2,4) of a (4,1,1) one")
         if self.algo >= 1 and not winograd_ok(self.Cin, self.k, self.s, self.p, self.d, lattice,
-                                              self.odim, self.idim):
+                                              self.odim, self.idim, self.algo):
             raise ValueError("coclr_amd: Winograd needs a (3,1,1) or (1,3,3) stride-1 'same' stencil, or the "
                              "(7,1,1) stride-2 pad-3 temporal stem conv on an even frame count")
         self.desc = ConvDesc(self.N, self.Cin, self.Cout, *self.idim, *self.odim, *self.k,
@@ -218,8 +228,13 @@ class ConvGeom:
                     c = (phi + P - k0) // st
                     kk, pp, od, ys, yo = [1, 1, 1], [0, 0, 0], list(self.idim), [1, 1, 1], [0, 0, 0]
                     kk[ax], pp[ax], od[ax], ys[ax], yo[ax] = nk, nk - 1 - c, m_phi, st, phi
+                    # 3- and 4-tap phases of a long clip through F(4,3) / F(2,4) (algo = 2, lattice-aware kernels)
+                    lat = (ys, yo, self.idim)
+                    algo = 2 if (WINOGRAD_PHASES and winograd_t4_pays(od) and nk in (3, 4) and
+                                 winograd_ok(self.Cout, tuple(kk), (1, 1, 1), tuple(pp), (1, 1, 1), lat,
+                                             tuple(od), self.odim, 2)) else 0
                     geom = ConvGeom(self.N, self.Cout, self.Cin, self.odim, kk, (1, 1, 1), pp,
-                                    odim=od, lattice=(ys, yo, self.idim))
+                                    odim=od, lattice=lat, algo=algo)
                     out.append((geom, k0, nk, st))
         self._cache["phases"] = out
         return out

@@ -32,8 +32,8 @@ def conv_pack_weights(w, packed, cout, cin, taps, co_stride, ci_stride, tap_base
     transpose = bool(int(transpose) & 1)
     if wino:
         # the double keeps the plain stencil (3, 7 or 9 taps) in the first slots of the 4 / 6 / 9 / 16-slot operand
-        real = {4: 3, 6: 3, 9: 7, 16: 9}[taps]
-        w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, real), (co_stride, ci_stride, 1), 0)
+        real = {4: 3, 5: 4, 6: 3, 9: 7, 16: 9}[taps]
+        w3 = torch.as_strided(w.detach().reshape(-1), (cout, cin, real), (co_stride, ci_stride, tap_step), tap_base)
         r, c = (cout, cin) if transpose else (cin, cout)
         dst = packed.view(taps, _r32(r), _r128(c))
         dst.zero_()
@@ -64,7 +64,7 @@ def conv_pack_batch(table, blockmap, requests=None):
 def _unpack(geom, wp):
     taps = geom.taps
     if getattr(geom, "algo", 0) >= 1:
-        slots = (6 if geom.algo == 2 else 4) if taps == 3 else (9 if taps == 7 else 16)
+        slots = {3: 6 if geom.algo == 2 else 4, 4: 5, 7: 9, 9: 16}[taps]
         w = wp.view(slots, _r32(geom.Cin), _r128(geom.Cout))[:taps, :geom.Cin, :geom.Cout]
         return w.permute(2, 1, 0).reshape(geom.Cout, geom.Cin, *geom.k).contiguous()
     w = wp.view(taps, _r32(geom.Cin), _r128(geom.Cout))[:, :geom.Cin, :geom.Cout]

@@ -93,7 +93,7 @@ def test_conv_adjoint_identities_every_layer_full_size(network, at_least):
             phases = g.dgrad_phases()
             if phases is not None:
                 for pg, k0, nk, step in phases:
-                    ops.conv_fwd(pg, dy, run.pack(w, True, taps=nk, tap_base=k0, tap_step=step), dx)
+                    ops.conv_fwd(pg, dy, run.pack(w, True, taps=nk, tap_base=k0, tap_step=step, algo=pg.algo), dx)
             else:
                 ops.conv_fwd(g.dgrad(), dy, run.pack(w, True), dx)
             e_d = abs(_dot(x, dx) - ref) / scale

@@ -107,12 +107,16 @@ def test_conv_dgrad_wgrad(case):
     close(dw, w.grad, what="wgrad")
 
 
-@pytest.mark.parametrize("T", [8, 9, 32])
-def test_conv_dgrad_phase_decomposition(T):
+@pytest.mark.parametrize("wino", [True, False], ids=["winograd_phases", "direct_phases"])
+@pytest.mark.parametrize("T", [8, 9, 32, 34, 37])
+def test_conv_dgrad_phase_decomposition(T, wino, monkeypatch):
     """Strided temporal stem conv (backbone/s3dg.py:41): its data gradient as two dense
-    stride-1 correlations writing the even / odd frames of dX, plain and accumulated."""
+    stride-1 correlations writing the even / odd frames of dX, plain and accumulated.  From 16 frames per phase
+    up the 3-tap phase runs through F(4,3) and the 4-tap one through F(2,4) (algo = 2 with a destination lattice
+    along T; COCLR_WINO_PHASES=0 keeps the direct kernels)."""
     from coclr_amd import ops, engine
-    N, Cin, Cout, dims, k, s, p = 2, 64, 64, (T, 12, 12), (7, 1, 1), (2, 1, 1), (3, 0, 0)
+    monkeypatch.setattr(ops, "WINOGRAD_PHASES", wino)
+    N, Cin, Cout, dims, k, s, p = 2, 64, 72, (T, 12, 12), (7, 1, 1), (2, 1, 1), (3, 0, 0)
     torch.manual_seed(5)
     x = torch.randn(N, Cin, *dims, requires_grad=True)
     w = (torch.randn(Cout, Cin, *k) * 0.05).requires_grad_(True)
@@ -123,14 +127,17 @@ def test_conv_dgrad_phase_decomposition(T):
     phases = g.dgrad_phases()
     assert phases is not None and len(phases) == 2
     assert sorted(nk for _, _, nk, _ in phases) == [3, 4]
+    for pg, _, nk, _ in phases:
+        # a phase is a 'same' convolution over dY's frames only when T is even; odd T keeps the direct kernels
+        assert pg.algo == (2 if (wino and pg.odim[0] >= 16 and pg.odim[0] == pg.idim[0]) else 0), (nk, pg)
     run = engine.Run(torch.device("cuda"), save=False)
     wd, dyd = dev(w.detach()), dev(dy)
     dx = torch.full((N, Cin, *dims), float("nan"), device="cuda")
     for pg, k0, nk, step in phases:
-        ops.conv_fwd(pg, dyd, run.pack(wd, True, taps=nk, tap_base=k0, tap_step=step), dx)
+        ops.conv_fwd(pg, dyd, run.pack(wd, True, taps=nk, tap_base=k0, tap_step=step, algo=pg.algo), dx)
     close(dx, x.grad, what="phase dgrad")
     for pg, k0, nk, step in phases:
-        ops.conv_fwd(pg, dyd, run.pack(wd, True, taps=nk, tap_base=k0, tap_step=step), dx,
+        ops.conv_fwd(pg, dyd, run.pack(wd, True, taps=nk, tap_base=k0, tap_step=step, algo=pg.algo), dx,
                      accumulate=True)
     close(dx, 2 * x.grad, what="phase dgrad accumulate")
     # geometries outside the supported form fall back to the dilated formulation
