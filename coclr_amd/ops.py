@@ -88,6 +88,7 @@ WINOGRAD_HW = os.environ.get("COCLR_WINOGRAD_HW", "1") != "0"
 WINOGRAD_T4 = os.environ.get("COCLR_WINO_T4", "1") != "0"
 WINOGRAD_POLY7 = os.environ.get("COCLR_WINO_POLY7", "1") != "0"
 WINOGRAD_PHASES = os.environ.get("COCLR_WINO_PHASES", "1") != "0"
+_WINO_HW_MIN = int(os.environ.get("COCLR_WINO_HW_MIN", "16"))      # smallest map side that takes F(2x2,3x3)
 
 
 def winograd_ok(cin, k, s, p, d, lattice, odim=None, idim=None, algo=1):
@@ -134,7 +135,7 @@ def winograd_pays(cin, k, s, p, odim, idim=None):
         # measured at the benchmark shape only (32 -> 16 frames: 1.28 -> 1.09 ms, profiles/r06_poly7_ab.txt);
         # shorter clips keep the direct kernel
         return odim[0] >= 16
-    return tuple(k) != (1, 3, 3) or (odim[1] >= 16 and odim[2] >= 16)
+    return tuple(k) != (1, 3, 3) or (odim[1] >= _WINO_HW_MIN and odim[2] >= _WINO_HW_MIN)
 
 
 def winograd_t4_pays(odim):
