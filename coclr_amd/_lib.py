@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -35,7 +35,7 @@ class ConvCall(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("x", vp), ("w_packed", vp), ("y", vp), ("stats", vp),
                 ("bias", vp), ("ep_scale", vp), ("ep_shift", vp), ("n_index", vp), ("relu", i32),
                 ("accumulate", i32), ("bwd_y", vp), ("bwd_scale", vp), ("bwd_shift", vp), ("bwd_mean", vp),
-                ("bwd_invstd", vp), ("bwd_relu", i32), ("reserved", i32)]
+                ("bwd_invstd", vp), ("bwd_relu", i32), ("in_relu", i32), ("in_scale", vp), ("in_shift", vp)]
 
 
 class BnFwdCall(C.Structure):

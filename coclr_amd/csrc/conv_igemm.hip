@@ -79,6 +79,11 @@ struct ConvArgs {
   int relu, accumulate;
   int xcd;                // remap workgroup ids so that an XCD owns contiguous tiles
   int To_full;            // F(4,3) / F(2,4) temporal kernels: output frames of the launch (a.To counts groups)
+  // the input is the raw output of a BatchNorm(+ReLU) unit: x' = max?(x * in_scale[ci] + in_shift[ci], 0) is
+  // applied while the kernel reads (conv_poly7_body INAFF), zero padding stays zero
+  const float* in_scale;
+  const float* in_shift;
+  int in_relu;
 };
 
 // sum over each 16-lane row (result in every lane of the row)
@@ -1622,7 +1627,7 @@ conv_wino_t24_kernel(const ConvArgs a) {
 //     y[2p] = (m0+m1+m2) + (n0+n1+n2+n3)        y[2p+1] = (m1-m2-m3) + (n1-n2+2n3+n4)
 // Same structure as the temporal Winograd kernels above: a (9,1,1) stencil with temporal stride 4 over output-pair
 // positions, nine accumulator sets per 32x32 block (144 registers: two workgroups per CU).
-template <int CC, int BM, int BNQ, int PCH, bool XV4>
+template <int CC, int BM, int BNQ, int PCH, bool XV4, bool INAFF = false>
 __device__ __forceinline__ void conv_poly7_body(const ConvArgs& a, int bid, const int nblocks) {
   constexpr int TAPS = 9;
   constexpr int WM = 2, WN = 2;
@@ -1728,6 +1733,30 @@ __device__ __forceinline__ void conv_poly7_body(const ConvArgs& a, int bid, cons
   }
   const int abase = half * BM + wm * (BM / WM) + l31;
 
+  // INAFF: the window holds the raw output of the producing BatchNorm unit.  Its per-channel (scale, shift) sit
+  // in LDS behind the stages; frames outside [0, Ti) -- r0..r2 of the first output pair, r5..r8 of the last --
+  // must stay ZERO after the affine (they are the convolution's zero padding): a 0 / 1 factor per lane
+  float* aff = smem + (a.nchunks > 1 ? 2 : 1) * stage_floats;
+  float fm[INAFF ? NF : 1][7];
+  if (INAFF) {
+    for (int c = tid; c < a.CinP; c += 256) {
+      aff[c] = c < a.Cin ? a.in_scale[c] : 0.f;
+      aff[a.CinP + c] = c < a.Cin ? a.in_shift[c] : 0.f;
+    }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int p = wn * (BNQ / WN) + nf * 32 + l31;
+      const int tt = (p >> (a.lTW + a.lTH)) & ((1 << a.lTT) - 1);
+      const int f0 = 4 * (ot0 + tt) - 3;                 // input frame of r0
+#pragma unroll
+      for (int j = 0; j < 3; ++j) fm[nf][j] = f0 + j >= 0 ? 1.f : 0.f;
+      // (r3, r4 feed a valid output frame whenever the pair has one; r5, r6 run past the end only in the last
+      // pair of an odd output-frame count)
+#pragma unroll
+      for (int j = 5; j < 9; ++j) fm[nf][j - 2] = f0 + j < a.Ti ? 1.f : 0.f;
+    }
+  }
+
   f32x16 acc[MF][NF][9];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
@@ -1804,7 +1833,19 @@ __device__ __forceinline__ void conv_poly7_body(const ConvArgs& a, int bid, cons
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
-        const float* r_ = dv[q & 1][nf];
+        float* r_ = dv[q & 1][nf];
+        if (INAFF) {
+          const int c = ch * CC + 2 * q + half;
+          const float sc = aff[c], sh = aff[a.CinP + c];
+#pragma unroll
+          for (int j = 0; j < 9; ++j) {
+            float v_ = fmaf(r_[j], sc, sh);
+            if (a.in_relu) v_ = fmaxf(v_, 0.f);
+            r_[j] = v_;
+          }
+          r_[0] *= fm[nf][0]; r_[1] *= fm[nf][1]; r_[2] *= fm[nf][2];
+          r_[5] *= fm[nf][3]; r_[6] *= fm[nf][4]; r_[7] *= fm[nf][5]; r_[8] *= fm[nf][6];
+        }
         // odd taps (w1, w3, w5) on frames r1, r3, r5, r7: F(2,3); even taps (w0, w2, w4, w6) on r0, r2, r4, r6, r8: F(2,4)
         const float e0 = r_[1], e1 = r_[3], e2 = r_[5], e3 = r_[7];
         const float o0 = r_[0], o1 = r_[2], o2 = r_[4], o3 = r_[6], o4 = r_[8];
@@ -1924,10 +1965,10 @@ __device__ __forceinline__ void conv_poly7_body(const ConvArgs& a, int bid, cons
 }
 
 
-template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC = 1>
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC = 1, bool INAFF = false>
 __global__ void __launch_bounds__(256, OCC)
 conv_poly7_kernel(const ConvArgs a) {
-  conv_poly7_body<CC, BM, BNQ, PCH, XV4>(a, (int)blockIdx.x, (int)gridDim.x);
+  conv_poly7_body<CC, BM, BNQ, PCH, XV4, INAFF>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 
@@ -3547,19 +3588,19 @@ int launch_wino_t24(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   return 0;
 }
 
-template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC>
+template <int CC, int BM, int BNQ, int PCH, bool XV4, int OCC, bool INAFF = false>
 int launch_poly7(ConvArgs& a, ConvPlan& p, hipStream_t stream) {
   if (p.plane > PCH * 64) return COCLR_EINVAL;
   a.mtiles = cdiv(a.Cout, BM);
   a.planeS = XV4 ? p.plane : cdiv(p.plane, 64) * 64;
   a.nchunks = cdiv(a.Cin, CC);
   const size_t stage = ((size_t)9 * CC * BM + (size_t)CC * a.planeS) * sizeof(float);
-  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1);
+  const size_t lds_main = stage * (a.nchunks > 1 ? 2 : 1) + (INAFF ? (size_t)2 * a.CinP * sizeof(float) : 0);
   const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   if (lds > 160 * 1024) return COCLR_EINVAL;
   const long blocks = (long)a.mtiles * a.ntiles;
-  auto kern = conv_poly7_kernel<CC, BM, BNQ, PCH, XV4, OCC>;
+  auto kern = conv_poly7_kernel<CC, BM, BNQ, PCH, XV4, OCC, INAFF>;
   static std::atomic<uint64_t> attr_done{0};
   COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
@@ -3876,6 +3917,12 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
   a.ntiles = p.ntiles; a.mtiles = 0; a.planeS = 0; a.nchunks = 0;
   a.relu = relu; a.accumulate = accumulate;
   a.To_full = 0;
+  a.in_scale = a.in_shift = nullptr; a.in_relu = 0;
+  if (bw && bw->in_scale) {
+    // consumer-side BatchNorm apply: only the kernel that has the operand path for it, never with a gather
+    if (variant != 41 || !bw->in_shift || n_index) return COCLR_EINVAL;
+    a.in_scale = bw->in_scale; a.in_shift = bw->in_shift; a.in_relu = bw->in_relu;
+  }
   {
     static const bool xcd_off = getenv("COCLR_XCD_MAP") && atoi(getenv("COCLR_XCD_MAP")) == 0;
     a.xcd = !xcd_off;
@@ -4020,6 +4067,9 @@ int conv3d_fwd_impl(const coclr_conv_desc* d, const float* x, const float* w_pac
                         (a.x_cstride % 4) == 0 && (a.x_nstride % 4) == 0 && ((uintptr_t)x % 16) == 0 &&
                         (p.plane % 4) == 0;
       if (n_index) return COCLR_EINVAL;
+      if (a.in_scale)
+        return xv4p ? launch_poly7<8, 64, 64, 6, true, 2, true>(a, p, stream)
+                    : launch_poly7<8, 64, 64, 6, false, 2, true>(a, p, stream);
       if (xv4p) return launch_poly7<8, 64, 64, 6, true, 2>(a, p, stream);
       return launch_poly7<8, 64, 64, 6, false, 2>(a, p, stream);
     }

@@ -716,7 +716,7 @@ def _exec(req):
         if c.get("want_stats"):
             nt = c["geom"].ntiles()
             stats = torch.empty(2 * c["geom"].Cout * nt, dtype=torch.float32, device=c["y"].device)
-        if c.get("bwd_bn") is not None:
+        if c.get("bwd_bn") is not None or c.get("in_affine") is not None:
             c["stats"] = stats
             ops.conv_fwd_multi([c])
         else:
@@ -876,7 +876,6 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
     Cout = w.shape[0]
     if w.shape[1] != Cin:
         raise ValueError("coclr_amd: conv expects %d input channels, got %d" % (w.shape[1], Cin))
-    xv = x.view()
     training = bn.training or (bn.running_mean is None)
 
     sliced = k[0] > 3 and k[1] > 1          # (5,7,7) stem: one launch per temporal tap
@@ -886,6 +885,18 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
         geoms = [ops.conv_geom(N, Cin, Cout, idim, k, s, p)]
         if n_index is not None and geoms[0].algo and k[1] > 1:
             geoms = [ops.ConvGeom(N, Cin, Cout, idim, k, s, p)]    # the gather lives in the direct kernel
+    # The input is a BatchNorm unit whose apply pass has not run (Val.lazy) and this convolution's kernel can apply
+    # relu(y * scale + shift) while it reads (the polyphase temporal stem conv): the normalised tensor -- 1 GB at
+    # B = 32 behind Conv_1a.conv1 -- is never written or re-read.  Only in passes that keep no tape: the weight
+    # gradient of this unit reads the normalised tensor.
+    in_affine = None
+    if IN_AFFINE and x.lazy is not None and x.lazy != "consumed" and x.whole and not run.save and \
+            n_index is None and not sliced and want_in_affine(geoms[0], training or run.save):
+        ysrc, sc_in, sh_in, relu_in = x.lazy
+        x.lazy = "consumed"
+        xv, in_affine = ysrc, (sc_in, sh_in, relu_in)
+    else:
+        xv = x.view()
     odim = geoms[0].odim
     want_y = training or run.save or residual is not None
 
@@ -902,7 +913,8 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
         for t, g in enumerate(geoms):
             last = t == len(geoms) - 1
             res = yield ("conv", dict(geom=g, x=xv, w=run.pack(w, False, t if sliced else None, algo=g.algo),
-                                      y=y, want_stats=training and last, n_index=n_index, accumulate=t > 0))
+                                      y=y, want_stats=training and last, n_index=n_index, accumulate=t > 0,
+                                      in_affine=in_affine))
             if training and last:
                 stats, ntiles = res
         count = N * odim[0] * odim[1] * odim[2]
@@ -1025,6 +1037,14 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
 
 
 LAZY_APPLY = os.environ.get("COCLR_LAZY_APPLY", "1") != "0"
+# BatchNorm + ReLU of a unit applied by the CONVOLUTION that consumes it (gradient-free passes, kernels that can)
+IN_AFFINE = os.environ.get("COCLR_IN_AFFINE", "1") != "0"
+
+
+def want_in_affine(geom, keeps_y):
+    """Can (and should) the kernel of `geom` apply the producing unit's BatchNorm + ReLU while it reads?  The
+    polyphase temporal stem conv, in the form that writes y (train-mode statistics or a kept tape)."""
+    return keeps_y and geom.k == (7, 1, 1) and geom.algo == 1
 # BatchNorm backward sums in the epilogue of the data gradient that writes the unit's dz (single writer):
 # one read of y there instead of the reduction pass over dz and y.  OPT-IN: measured on an MI355X at B=32
 # (tools/r04_flaky.sh, four alternating pairs) it is worth nothing -- 1030.9 vs 1031.1 clips/s -- because

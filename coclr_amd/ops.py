@@ -399,6 +399,10 @@ def conv_fwd_multi(calls):
         a.n_index = _p(c.get("n_index"), torch.int64)
         a.relu = 0
         a.accumulate = int(bool(c.get("accumulate", False)))
+        ia = c.get("in_affine")
+        if ia is not None:
+            # (scale, shift, relu) of the BatchNorm unit whose raw output x is: applied while the kernel reads
+            a.in_scale, a.in_shift, a.in_relu = _p(ia[0]), _p(ia[1]), int(bool(ia[2]))
         bb = c.get("bwd_bn")
         if bb is not None:
             # (y, scale, shift, mean, invstd, relu) of the BatchNorm unit whose dz this data gradient writes

@@ -146,7 +146,16 @@ typedef struct coclr_conv_call {
   const float* bwd_shift;
   const float* bwd_mean;
   const float* bwd_invstd;
-  int32_t bwd_relu, reserved;
+  int32_t bwd_relu;
+  /* The input x is the RAW convolution output of a BatchNorm(+ReLU) unit whose apply pass has not run:
+   * the kernel applies x' = x * in_scale[ci] + in_shift[ci] (max(., 0) when in_relu) to every element it
+   * reads, zero padding staying zero -- the normalised tensor is never written or re-read (the apply pass
+   * of backbone/s3dg.py:46-48 fused into the NEXT convolution of the separable unit, :49).  Only the
+   * kernels that move their B operand through registers support it (the polyphase temporal stem conv);
+   * COCLR_EINVAL otherwise.  NULL: a plain call. */
+  int32_t in_relu;
+  const float* in_scale;
+  const float* in_shift;
 } coclr_conv_call;
 int coclr_conv3d_fwd_multi(const coclr_conv_call* calls, int n, void* stream);
 int coclr_conv3d_bwd_sums_ok(const coclr_conv_desc* d, int* ok);

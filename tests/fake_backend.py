@@ -130,6 +130,11 @@ def conv_fwd_multi(calls):
     """The pair / multi entry point: every problem on its own."""
     for c in calls:
         bb = c.get("bwd_bn")
+        ia = c.get("in_affine")
+        if ia is not None:
+            # the raw output of a BatchNorm unit, normalised while the convolution reads it
+            xa = c["x"] * _b(ia[0]) + _b(ia[1])
+            c = dict(c, x=torch.relu(xa) if ia[2] else xa)
         conv_fwd(c["geom"], c["x"], c["w"], c["y"], stats=None if bb is not None else c.get("stats"),
                  n_index=c.get("n_index"), accumulate=c.get("accumulate", False))
         if bb is not None:

@@ -737,7 +737,7 @@ def test_conv_temporal_stem_polyphase_winograd(case):
     contractions per pair of output frames instead of fourteen) against F.conv3d and against the direct kernel:
     forward with BatchNorm partial sums, accumulate form, inference epilogue; odd output frame counts, ragged
     channels.  The data gradient of this conv runs in phases (ConvGeom.dgrad_phases), not here."""
-    from coclr_amd import ops, engine
+    from coclr_amd import ops, engine, _lib
     N, Cin, Cout, dims = case
     k, s, p = (7, 1, 1), (2, 1, 1), (3, 0, 0)
     torch.manual_seed(16)
@@ -770,6 +770,22 @@ def test_conv_temporal_stem_polyphase_winograd(case):
     sc, sf = torch.rand(Cout) + 0.5, torch.randn(Cout)
     ops.conv_fwd(g, xd, run.pack(wd, False, algo=1), y, ep_scale=dev(sc), ep_shift=dev(sf), relu=True)
     close(y, torch.relu(ref * sc.view(1, -1, 1, 1, 1) + sf.view(1, -1, 1, 1, 1)), what="polyphase affine+relu epilogue")
+    # consumer-side BatchNorm apply (coclr_conv_call.in_scale / in_shift): x is the RAW output of the unit in
+    # front; zero padding must stay zero AFTER the affine (relu(shift) != 0)
+    isc, ish = torch.rand(Cin) + 0.5, torch.randn(Cin)
+    for relu_in in (True, False):
+        xz = x * isc.view(1, -1, 1, 1, 1) + ish.view(1, -1, 1, 1, 1)
+        xz = torch.relu(xz) if relu_in else xz
+        refz = F.conv3d(xz, w, None, s, p)
+        stz = torch.empty(2 * Cout * g.ntiles(), device="cuda")
+        ops.conv_fwd_multi([dict(geom=g, x=xd, w=run.pack(wd, False, algo=1), y=y, stats=stz,
+                                 in_affine=(dev(isc), dev(ish), relu_in))])
+        close(y, refz, what="polyphase with the producing unit's BatchNorm%s applied on load"
+              % ("+ReLU" if relu_in else ""))
+        close(stz.view(2, Cout, -1).double().sum(-1).cpu()[1], (refz.double() ** 2).sum((0, 2, 3, 4)),
+              what="its statistics")
+    with pytest.raises(_lib.HipLibraryError):          # the direct kernel has no operand path for it
+        ops.conv_fwd_multi([dict(geom=g0, x=xd, w=run.pack(wd, False), y=y, in_affine=(dev(isc), dev(ish), True))])
     # into a channel slice of a wider tensor, from a channel slice of a wider input
     wide = torch.zeros(N, Cout + 8, *g.odim, device="cuda")
     xw = torch.zeros(N, Cin + 4, *dims, device="cuda")
