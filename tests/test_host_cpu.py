@@ -297,7 +297,26 @@ def test_winograd_policy():
     with pytest.raises(ValueError):
         ops.ConvGeom(2, 32, 48, (3, 7, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1), algo=1)
     with pytest.raises(ValueError):
-        ops.ConvGeom(2, 32, 48, (3, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0), algo=2)
+        ops.ConvGeom(2, 32, 48, (3, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0), algo=3)
+    with pytest.raises(ValueError):
+        ops.ConvGeom(2, 32, 48, (3, 8, 8), (1, 3, 3), (1, 1, 1), (0, 1, 1), algo=2)
+    # round 6: F(4,3) (algo 2) for the temporal layers from 16 frames up; the stride-2 temporal stem conv in
+    # polyphase form (algo 1 on that stencil) at the benchmark clip length, its data gradient in two Winograd
+    # phases that write through a lattice along T
+    if ops.WINOGRAD_T4:
+        assert ops.conv_geom(4, 192, 192, (16, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0)).algo == 2
+        assert ops.conv_geom(4, 192, 192, (16, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0)).dgrad().algo == 2
+        assert ops.ConvGeom(2, 32, 48, (3, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0), algo=2).algo == 2    # capability
+    if ops.WINOGRAD_POLY7:
+        stem = ops.conv_geom(4, 64, 64, (32, 16, 16), (7, 1, 1), (2, 1, 1), (3, 0, 0))
+        assert stem.algo == 1 and stem.dgrad().algo == 0
+        assert ops.conv_geom(4, 64, 64, (16, 16, 16), (7, 1, 1), (2, 1, 1), (3, 0, 0)).algo == 0
+        with pytest.raises(ValueError):
+            ops.ConvGeom(4, 64, 64, (31, 16, 16), (7, 1, 1), (2, 1, 1), (3, 0, 0), algo=1)
+        if ops.WINOGRAD_T4 and ops.WINOGRAD_PHASES:
+            phases = stem.dgrad_phases()
+            assert sorted((nk, pg.algo) for pg, _, nk, _ in phases) == [(3, 2), (4, 2)]
+            assert all(pg.lattice[0][0] == 2 for pg, _, _, _ in phases)
 
 
 def test_forward_without_backward_releases_the_tape(fake):
