@@ -21,6 +21,10 @@ import threading
 from . import _lib
 
 _ACTIVE = None          # the Recorder of the thread that is recording, if any
+# Measurement hook (bench.py): PROBE(key, start event, end event) receives HIP events recorded around the entries a
+# caller marked while the plan was recorded (LaunchPlan.marks) -- the re-issued launches of one kernel cannot be
+# bracketed from outside any more.  None (the default): replay does not look at the marks.
+PROBE = None
 
 # host-side queries (no launch, results cached by their callers): never part of a plan
 _QUERIES = frozenset((
@@ -42,15 +46,19 @@ def active():
 class LaunchPlan:
     """An ordered log of (C function, frozen arguments) and of Python callables (stream dependencies)."""
 
-    __slots__ = ("entries", "keep", "ncalls", "stream")
+    __slots__ = ("entries", "keep", "ncalls", "stream", "marks")
 
     def __init__(self, stream):
         self.entries = []      # (fn, args list) | (None, callable)
         self.keep = []         # ctypes objects the frozen arguments point into
         self.ncalls = 0
         self.stream = stream   # handle of the stream the pass was recorded on (replay must be on it)
+        self.marks = []        # (first entry, one past the last entry, key): ranges a measurement brackets
 
     def replay(self):
+        probe = PROBE
+        if probe is not None and self.marks:
+            return self._replay_probed(probe)
         for fn, args in self.entries:
             if fn is None:
                 args()
@@ -59,6 +67,30 @@ class LaunchPlan:
                 if rc != 0:
                     raise _lib.HipLibraryError("coclr_amd: %s failed with hipError %d (launch plan replay)"
                                                % (fn.__name__, rc))
+        _lib.CALLS[0] += self.ncalls
+
+    def _replay_probed(self, probe):
+        """replay() with HIP events on the current stream around the marked ranges."""
+        import torch
+        begins = {b: k for b, e, k in self.marks}
+        ends = {e: k for b, e, k in self.marks}
+        pending = {}
+        for i, (fn, args) in enumerate(self.entries):
+            if i in begins:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                pending[begins[i]] = ev
+            if fn is None:
+                args()
+            else:
+                rc = fn(*args)
+                if rc != 0:
+                    raise _lib.HipLibraryError("coclr_amd: %s failed with hipError %d (launch plan replay)"
+                                               % (fn.__name__, rc))
+            if i + 1 in ends and ends[i + 1] in pending:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                probe(ends[i + 1], pending.pop(ends[i + 1]), ev)
         _lib.CALLS[0] += self.ncalls
 
     def pointer_refs(self, lo, hi):
