@@ -682,7 +682,7 @@ def test_bench_degradation_ladder(fault, rung, attempts):
       routed_hangs     one rank never enters the exchange: the watchdog names it after --hang-timeout and
                        ends the attempt; same recovery"""
     rec, err = _bench_dry_run(2, 29750 + rung + attempts, {"COCLR_BENCH_FAULT": fault},
-                              ("--hang-timeout", "6"))
+                              ("--hang-timeout", "10"))      # 6 s flaked once on a loaded 8-core host
     mg = rec["multi_gpu"]
     assert rec["value"] > 0 and rec["n_gpus"] == 2
     assert mg["rung"] == rung, (mg["rung"], mg["attempts"], rec["self_check"]["trials"])
