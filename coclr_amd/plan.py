@@ -12,7 +12,7 @@ gradient and workspace then has an address nobody else is given) while `Recorder
 makes -- function pointer plus arguments frozen as ctypes objects, descriptors copied -- and every stream
 dependency (engine._note).  Every later pass re-issues the log: same kernels, same operands, same streams, same
 order -- eager launches, not a hipGraph (whose replay serialises the weight-gradient branch on ROCm: -5 % on
-the device) -- at ~2 us of host time per call.  Results are bit-identical to the
+the device, docs/history.md section 2) -- at ~2 us of host time per call.  Results are bit-identical to the
 interpreted pass (tests/test_gpu_model.py::test_planned_query_encoder_matches_eager).
 """
 import ctypes as C

@@ -58,8 +58,15 @@ typedef struct coclr_conv_desc {
                               (3,1,1) stencil, stride 1, pad (1,0,0): F(2,3) along T, taps = 4;
                               (1,3,3) stencil, stride 1, pad (0,1,1), even Ho/Wo >= 4, dense
                               destination, no n_index: F(2x2,3x3), taps = 16;
+                              (7,1,1) stencil, stride (2,1,1), pad (3,0,0), Ti = 2 To, >= 8 output
+                              frames, dense destination, no n_index: polyphase form of the temporal stem
+                              conv (backbone/s3dg.py:41,145) -- F(2,3) on the odd taps + F(2,4) on the even
+                              ones, taps = 9 (forward operand only);
                               2: (3,1,1) stencil, stride 1, pad (1,0,0), no n_index: F(4,3) along T,
-                              taps = 6 (six contractions per quad of output frames) */
+                              taps = 6 (six contractions per quad of output frames);
+                              (4,1,1) stencil, stride 1, pad (1,0,0), To = Ti: F(2,4) along T, taps = 5.
+                              The algo = 2 kernels also write through a destination lattice along T
+                              (ys_t > 0, ys_h = ys_w = 1): the two phases of a strided temporal data gradient */
 } coclr_conv_desc;
 
 /* Number of fp32 elements of the packed-weight buffer for one conv. */
@@ -70,7 +77,9 @@ int coclr_conv_packed_size(int cin, int cout, int taps, int transpose, int64_t* 
  * transpose=0: operand of the forward conv (R = Cin, C = Cout); transpose=1: operand of
  * the data gradient (R = Cout, C = Cin, stencil flipped); transpose | 2: Winograd operand
  * (coclr_conv_desc.algo >= 1) -- taps = 4: the four F(2,3) matrices of a 3-tap temporal stencil,
- * taps = 6: its six F(4,3) matrices (algo = 2),
+ * taps = 6: its six F(4,3) matrices (algo = 2), taps = 5: the five F(2,4) matrices of a 4-tap temporal stencil,
+ * taps = 9: the 4 + 5 polyphase matrices of the 7-tap stride-2 stem conv (the source taps are then tap_base +
+ * t*tap_step, t = 0..6; transpose = 0 only),
  * taps = 16: the sixteen F(2x2,3x3) matrices U = G g G^T of a 9-tap spatial stencil, laid out
  * [R'][C'][16] (stand-alone operands only).  co/ci strides, tap_base and
  * tap_step address a sub-stencil: source tap of packed tap t is tap_base + t*tap_step
