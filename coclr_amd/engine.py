@@ -1520,6 +1520,7 @@ def _capture_backward(ent, dout):
 # COCLR_PLAN=0 switches it off (the interpreted pass); hipGraph replay (COCLR_GRAPH_QUERY) takes precedence.
 PLAN = os.environ.get("COCLR_PLAN", "1") != "0"
 _PLAN_WARMUP = 4            # interpreted passes first: one-time allocations, DDP's bucket rebuild, slot verification
+_PLAN_MAX_SHAPES = 3        # input shapes per node that get a plan (and a pool of activations) of their own
 PLAN_STATS = {"recorded": 0, "replayed": 0, "disabled": []}
 
 
@@ -1565,6 +1566,8 @@ def _plan_entry(module, x, params, kwargs):
     sig = _plan_signature(module, x, params)
     key = (tuple(x.shape), bool(x.requires_grad))
     ent = store.get(key)
+    if ent is None and len(store) >= _PLAN_MAX_SHAPES:
+        return None                              # every entry keeps a memory pool: odd shapes run interpreted
     if ent is None or ent.sig != sig:
         if ent is not None:
             _plan_drop(ent)
@@ -1672,6 +1675,8 @@ class PlanFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         ent = ctx.ent
+        if ent is None:
+            raise RuntimeError("coclr_amd: backbone backward called twice (graph not retained)")
         if ctx.version != ent.version:
             raise RuntimeError(
                 "coclr_amd: backward through a planned encoder pass whose activations a later forward has "

@@ -89,6 +89,7 @@ WINOGRAD_T4 = os.environ.get("COCLR_WINO_T4", "1") != "0"
 WINOGRAD_POLY7 = os.environ.get("COCLR_WINO_POLY7", "1") != "0"
 WINOGRAD_PHASES = os.environ.get("COCLR_WINO_PHASES", "1") != "0"
 _WINO_HW_MIN = int(os.environ.get("COCLR_WINO_HW_MIN", "16"))      # smallest map side that takes F(2x2,3x3)
+_WINO_T4_MIN = int(os.environ.get("COCLR_WINO_T4_MIN", "16"))      # fewest frames that take F(4,3)
 
 
 def winograd_ok(cin, k, s, p, d, lattice, odim=None, idim=None, algo=1):
@@ -143,7 +144,7 @@ def winograd_t4_pays(odim):
     16 frames (Conv_2c.conv2 0.754 -> 0.598 ms forward, Mixed_3c.b1.conv2 0.185 -> 0.145) yes; 8 frames (Mixed_4f
     0.080 -> 0.083) and 4 frames (Mixed_5c 0.050 -> 0.068: one quad per position, a third of the window is padding,
     three workgroups per CU instead of four) no."""
-    return WINOGRAD_T4 and odim[0] >= 16
+    return WINOGRAD_T4 and odim[0] >= _WINO_T4_MIN
 
 
 class ConvGeom:
