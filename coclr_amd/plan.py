@@ -66,7 +66,7 @@ class LaunchPlan:
                 rc = fn(*args)
                 if rc != 0:
                     raise _lib.HipLibraryError("coclr_amd: %s failed with hipError %d (launch plan replay)"
-                                               % (fn.__name__, rc))
+                                               % (getattr(fn, "__name__", "a C-ABI call"), rc))
         _lib.CALLS[0] += self.ncalls
 
     def _replay_probed(self, probe):
@@ -86,7 +86,7 @@ class LaunchPlan:
                 rc = fn(*args)
                 if rc != 0:
                     raise _lib.HipLibraryError("coclr_amd: %s failed with hipError %d (launch plan replay)"
-                                               % (fn.__name__, rc))
+                                               % (getattr(fn, "__name__", "a C-ABI call"), rc))
             if i + 1 in ends and ends[i + 1] in pending:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()

@@ -862,3 +862,59 @@ def test_bn_backward_sums_formed_by_the_writing_data_gradient(fake, monkeypatch)
     for k in ga:
         ref = gb[k]
         assert (ga[k] - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-8, k
+
+
+def test_launch_plan_mechanics():
+    """coclr_amd/plan.py without a GPU: a log of (C function, frozen arguments) and Python callables is re-issued in
+    order; byref'd descriptors are COPIED at recording time (the shared geometry descriptors are rewritten by later
+    calls); top-level pointers into a moved input are found and patched, pointers embedded in by-pointer tables are
+    reported (the caller then does not follow a moved input); host-side queries are never logged."""
+    import ctypes as C
+    from coclr_amd import plan, _lib
+
+    class Desc(C.Structure):
+        _fields_ = [("n", C.c_int32), ("ptr", C.c_void_p)]
+
+    seen = []
+    CB = C.CFUNCTYPE(C.c_int, C.POINTER(Desc), C.c_void_p, C.c_int32, C.c_void_p)
+
+    def impl(d, p, k, stream):
+        seen.append((d.contents.n, d.contents.ptr, p, k, stream))
+        return 0
+    fn = CB(impl)
+    fn.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_int32, C.c_void_p]
+
+    class FakeLib:
+        coclr_conv3d_fwd = fn
+        coclr_conv3d_ntiles = fn           # a query name: passed through, never logged
+
+    rec = plan.Recorder(stream=7)
+    rec.proxy = plan._Proxy(rec, FakeLib())
+    shared = Desc(3, 0x5000)
+    rec.proxy.coclr_conv3d_fwd(C.byref(shared), 0x1000 + 64, 5, 7)
+    shared.n = 99                                   # the shared descriptor is rewritten by the next call
+    rec.py(lambda: seen.append("dependency"))
+    rec.proxy.coclr_conv3d_fwd(C.byref(shared), 0x9000, 6, 7)
+    rec.proxy.coclr_conv3d_ntiles(C.byref(shared), None, 0, None)
+    p = rec.plan
+    assert p.ncalls == 2 and len(p.entries) == 3 and p.stream == 7
+    del seen[:]
+    before = _lib.CALLS[0]
+    p.replay()
+    assert seen == [(3, 0x5000, 0x1040, 5, 7), "dependency", (99, 0x5000, 0x9000, 6, 7)]
+    assert _lib.CALLS[0] == before + 2
+    # the input that lived at [0x1000, 0x2000) moved to 0x7000: one top-level reference, offset 64
+    refs = p.pointer_refs(0x1000, 0x2000)
+    assert refs == [(0, 1, 64)]
+    p.patch(refs, 0x7000)
+    del seen[:]
+    p.replay()
+    assert seen[0] == (3, 0x5000, 0x7040, 5, 7)
+    # an address inside a struct handed over by pointer is not patched -- it is reported
+    assert p.embedded_refs(0x5000, 0x5008) and not p.embedded_refs(0x6000, 0x6100)
+    # a failing call raises with the entry's name
+    bad = CB(lambda d, q, k, s: 719)
+    bad.argtypes = fn.argtypes
+    p.entries.append((bad, [None, None, C.c_int32(0), None]))
+    with pytest.raises(_lib.HipLibraryError):
+        p.replay()

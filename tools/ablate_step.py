@@ -29,28 +29,23 @@ elif fam == "pool":
 elif fam == "wgrad":
     ops.conv_wgrad = skip
 elif fam == "dgrad":
-    real_fwd, real_multi = ops.conv_fwd, ops.conv_fwd_multi
-    is_dgrad = lambda g: tuple(g.d) != (1, 1, 1) or g.lattice is not None or getattr(g, "_is_dgrad", False)
-    orig_dgrad = ops.ConvGeom.dgrad
+    # data gradients are conv_fwd calls on geometries made by ConvGeom.dgrad() / dgrad_phases() (a destination lattice)
+    real_fwd, real_multi, orig_dgrad = ops.conv_fwd, ops.conv_fwd_multi, ops.ConvGeom.dgrad
+    tags = set()
 
     def tagged(self):
         g = orig_dgrad(self)
-        try:
-            g._is_dgrad = True
-        except AttributeError:
-            pass
-        return g
-    # ConvGeom uses __slots__: tag through a side table instead
-    tags = set()
-
-    def tagged2(self):
-        g = orig_dgrad(self)
         tags.add(id(g))
         return g
-    ops.ConvGeom.dgrad = tagged2
-    ops.conv_fwd = lambda g, *a, **kw: None if (id(g) in tags or g.lattice is not None) else real_fwd(g, *a, **kw)
-    ops.conv_fwd_multi = lambda calls: real_multi([c for c in calls if not (id(c["geom"]) in tags)]) \
-        if any(id(c["geom"]) not in tags for c in calls) else None
+    ops.ConvGeom.dgrad = tagged
+    is_dgrad = lambda g: id(g) in tags or g.lattice is not None
+    ops.conv_fwd = lambda g, *a, **kw: None if is_dgrad(g) else real_fwd(g, *a, **kw)
+
+    def multi(calls):
+        keep = [c for c in calls if not is_dgrad(c["geom"])]
+        if keep:
+            real_multi(keep)
+    ops.conv_fwd_multi = multi
 import bench  # noqa: E402
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
 bench.main()
