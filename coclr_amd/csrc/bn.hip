@@ -68,7 +68,33 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
 // z = act(y*scale[c] + shift[c] (+ res)),  act = ReLU or identity.
 // y is contiguous [N][C][S]; z/res may live inside wider tensors (channel
 // slices of a concat buffer) -> explicit sample strides.
-template <bool VEC>
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+
+inline long bn_nt_bytes() {
+  const char* e = getenv("COCLR_BN_NT_MB");
+  const long mb = e ? atol(e) : 0;
+  return mb < 0 ? -1 : (mb << 20);
+}
+
+// 16-byte load / store, optionally NON-TEMPORAL: the streaming passes over tensors far larger than the 256 MB
+// infinity cache would otherwise evict what the MFMA-bound kernels of the other streams keep re-reading there
+__device__ __forceinline__ float4 ld4(const float* p, int i, bool nt) {
+  if (nt) {
+    const nt_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(p) + i);
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+  return reinterpret_cast<const float4*>(p)[i];
+}
+__device__ __forceinline__ void st4(float* p, int i, const float4& w, bool nt) {
+  if (nt) {
+    nt_f32x4 t; t.x = w.x; t.y = w.y; t.z = w.z; t.w = w.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f32x4*>(p) + i);
+  } else {
+    reinterpret_cast<float4*>(p)[i] = w;
+  }
+}
+
+template <bool VEC, bool NT = false>
 __global__ void __launch_bounds__(256)
 bn_act_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ res, float* z,
@@ -93,7 +119,12 @@ bn_act_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale
         for (int k = 0; k < 4; ++k) {
           const int i = i0 + k * stride;
           if (i < S4) {
-            v[k] = reinterpret_cast<const float4*>(yp)[i];
+            if (NT) {
+              const nt_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(yp) + i);
+              v[k] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+              v[k] = reinterpret_cast<const float4*>(yp)[i];
+            }
             if (rp) r[k] = reinterpret_cast<const float4*>(rp)[i];
           }
         }
@@ -109,7 +140,12 @@ bn_act_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale
               w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f);
               w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
             }
-            reinterpret_cast<float4*>(zp)[i] = w;
+            if (NT) {
+              nt_f32x4 t; t.x = w.x; t.y = w.y; t.z = w.z; t.w = w.w;
+              __builtin_nontemporal_store(t, reinterpret_cast<nt_f32x4*>(zp) + i);
+            } else {
+              reinterpret_cast<float4*>(zp)[i] = w;
+            }
           }
         }
       }
@@ -134,8 +170,10 @@ bn_act_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__
                          const float* __restrict__ z, const float* __restrict__ scale,
                          const float* __restrict__ shift, const float* __restrict__ mean,
                          const float* __restrict__ invstd, double* sums, int N, int C, int S,
-                         long dz_nstride, long y_nstride, long z_nstride, int relu) {
+                         long dz_nstride, long y_nstride, long z_nstride, int relu_nt) {
   __shared__ double red[4];
+  const int relu = relu_nt & 1;
+  const bool nt = (relu_nt & 2) != 0;
   const int c = blockIdx.x;
   const float sc = scale[c], sf = shift[c], mu = mean[c], is = invstd[c];
   double sg = 0.0, sgx = 0.0;
@@ -155,8 +193,8 @@ bn_act_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__
           const int i = i0 + k * 256;
           ok[k] = i < S4;
           if (ok[k]) {
-            dd[k] = reinterpret_cast<const float4*>(dzp)[i];
-            vv[k] = reinterpret_cast<const float4*>(yp)[i];
+            dd[k] = ld4(dzp, i, nt);
+            vv[k] = ld4(yp, i, nt);
             if (relu && zp) zq[k] = reinterpret_cast<const float4*>(zp)[i];
           }
         }
@@ -237,8 +275,10 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
                         int groups, double count, int training, float* dgamma, float* dbeta,
                         float* dy, float* dres, int N, int C, int S, long dz_nstride,
                         long y_nstride, long dy_nstride, long z_nstride, long dres_nstride,
-                        int relu, int dres_accumulate) {
+                        int relu_nt, int dres_accumulate) {
   __shared__ double tot[2];
+  const int relu = relu_nt & 1;
+  const bool nt = (relu_nt & 2) != 0;
   // blockIdx.y = (sample group, channel); the partial sums of the channel are folded once per
   // block, then the block walks its samples
   const int c = blockIdx.y % C, sgrp = blockIdx.y / C, nsg = gridDim.y / C;
@@ -282,8 +322,8 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
           const int i = i0 + k * stride;
           ok[k] = i < S4;
           if (ok[k]) {
-            dd[k] = reinterpret_cast<const float4*>(dzp)[i];
-            vv[k] = reinterpret_cast<const float4*>(yp)[i];
+            dd[k] = ld4(dzp, i, nt);
+            vv[k] = ld4(yp, i, nt);
             if (relu && zp) zq[k] = reinterpret_cast<const float4*>(zp)[i];
           }
         }
@@ -314,7 +354,7 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
           float4 o;
           o.x = fmaf(A, g.x, fmaf(B, v.x, D)); o.y = fmaf(A, g.y, fmaf(B, v.y, D));
           o.z = fmaf(A, g.z, fmaf(B, v.z, D)); o.w = fmaf(A, g.w, fmaf(B, v.w, D));
-          reinterpret_cast<float4*>(dyp)[i] = o;
+          st4(dyp, i, o, nt);
         }
       }
     } else {
@@ -760,7 +800,17 @@ extern "C" int coclr_bn_act_apply(const float* y, const float* scale, const floa
   const bool vec = (S % 4 == 0) && (y_nstride % 4 == 0) && (z_nstride % 4 == 0) &&
                    (!residual || res_nstride % 4 == 0);
   dim3 grid = plane_grid(N, C, (int)S);
-  if (vec)
+  // Non-temporal loads / stores in the streaming BatchNorm passes: they move tensors of up to 2 GB through a chip
+  // whose other streams run MFMA-bound kernels that live on what they keep re-reading from L2 / the 256 MB
+  // infinity cache (weights, stencil windows, split-K partials).  Measured inside the step, same box, alternating
+  // x4 (profiles/r06_bn_nontemporal_ab.txt): +1.3 % with every such pass non-temporal, +0.9 % with only the
+  // tensors above 200 MB.  COCLR_BN_NT_MB=<MB> sets the size from which a pass is non-temporal, -1 switches it off.
+  static const long nt_bytes = bn_nt_bytes();
+  if (vec && nt_bytes >= 0 && (long)N * C * S * 4 >= nt_bytes)
+    hipLaunchKernelGGL((bn_act_apply_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, y, scale,
+                       shift, residual, z, N, C, (int)S, (long)y_nstride, (long)z_nstride,
+                       (long)res_nstride, relu);
+  else if (vec)
     hipLaunchKernelGGL(bn_act_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y, scale,
                        shift, residual, z, N, C, (int)S, (long)y_nstride, (long)z_nstride,
                        (long)res_nstride, relu);
@@ -803,6 +853,9 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
     COCLR_LAUNCH_CHECK();
     return 0;
   }
+  static const long nt_bytes_b = bn_nt_bytes();          // see coclr_bn_act_apply
+  relu = relu ? 1 : 0;
+  if (nt_bytes_b >= 0 && vec && (long)N * C * S * 4 >= nt_bytes_b) relu |= 2;   // bit 1: non-temporal passes
   // pass 1: per (channel, sample group) partial sums of g and g*xhat
   const int groups = reduce_groups(N, (int)S);
   dim3 rgrid(C, groups);

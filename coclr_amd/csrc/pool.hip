@@ -27,7 +27,33 @@ struct PoolGeom {
   int in_relu;
   int C0;                      // channels before T was folded into the plane count
   int tfold;
+  int nt;                      // stream the big operand with non-temporal loads / stores (see pool_nt_bytes)
 };
+
+typedef float pool_f32x4 __attribute__((ext_vector_type(4)));
+
+// Non-temporal 16-byte access: the pooling passes over the stem's 1 GB tensors would otherwise evict what the
+// MFMA-bound kernels of the other streams keep re-reading from L2 / the infinity cache (csrc/bn.hip, same switch)
+__device__ __forceinline__ float4 pool_ld4(const float* p, int i, bool nt) {
+  if (nt) {
+    const pool_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const pool_f32x4*>(p) + i);
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+  return reinterpret_cast<const float4*>(p)[i];
+}
+__device__ __forceinline__ void pool_st4(float* p, int i, const float4& w, bool nt) {
+  if (nt) {
+    pool_f32x4 t; t.x = w.x; t.y = w.y; t.z = w.z; t.w = w.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<pool_f32x4*>(p) + i);
+  } else {
+    reinterpret_cast<float4*>(p)[i] = w;
+  }
+}
+inline long pool_nt_bytes() {
+  const char* e = getenv("COCLR_BN_NT_MB");
+  const long mb = e ? atol(e) : 0;
+  return mb < 0 ? -1 : (mb << 20);
+}
 
 __device__ __forceinline__ float pool_in(const PoolGeom& g, float v, int c) {
   if (g.in_scale) {
@@ -130,7 +156,7 @@ maxpool3d_tiled_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
     const int ch = c / g.tfold;          // channel of the un-folded tensor
     if ((Si & 3) == 0 && ((g.x_nstride & 3) == 0)) {
       for (int i = threadIdx.x; i < (Si >> 2); i += 256) {
-        float4 v = reinterpret_cast<const float4*>(xp)[i];
+        float4 v = pool_ld4(xp, i, g.nt != 0);
         v.x = pool_in(g, v.x, ch); v.y = pool_in(g, v.y, ch);
         v.z = pool_in(g, v.z, ch); v.w = pool_in(g, v.w, ch);
         reinterpret_cast<float4*>(tp)[i] = v;
@@ -591,7 +617,7 @@ bn_pool_bwd_apply_kernel(const float* __restrict__ pdy, const int* __restrict__ 
     if ((Si & 3) == 0 && ((y_nstride | dy_nstride) & 3) == 0) {
       for (int i = threadIdx.x; i < (Si >> 2); i += 256) {
         float4 gq = reinterpret_cast<const float4*>(tp)[i];
-        const float4 v = reinterpret_cast<const float4*>(yp)[i];
+        const float4 v = pool_ld4(yp, i, g.nt != 0);
         if (relu) {
           gq.x = fmaf(v.x, sc, sf) > 0.f ? gq.x : 0.f; gq.y = fmaf(v.y, sc, sf) > 0.f ? gq.y : 0.f;
           gq.z = fmaf(v.z, sc, sf) > 0.f ? gq.z : 0.f; gq.w = fmaf(v.w, sc, sf) > 0.f ? gq.w : 0.f;
@@ -599,7 +625,7 @@ bn_pool_bwd_apply_kernel(const float* __restrict__ pdy, const int* __restrict__ 
         float4 o;
         o.x = fmaf(A, gq.x, fmaf(B, v.x, D)); o.y = fmaf(A, gq.y, fmaf(B, v.y, D));
         o.z = fmaf(A, gq.z, fmaf(B, v.z, D)); o.w = fmaf(A, gq.w, fmaf(B, v.w, D));
-        reinterpret_cast<float4*>(dyp)[i] = o;
+        pool_st4(dyp, i, o, g.nt != 0);
       }
     } else {
       for (int i = threadIdx.x; i < Si; i += 256) {
@@ -750,6 +776,10 @@ inline PoolGeom to_geom(const coclr_pool_desc* d) {
   g.pt = d->pt; g.ph = d->ph; g.pw = d->pw;
   g.x_nstride = d->x_nstride; g.y_nstride = d->y_nstride;
   g.in_scale = g.in_shift = nullptr; g.in_relu = 0; g.C0 = d->C; g.tfold = 1;
+  {
+    static const long nt_bytes = pool_nt_bytes();
+    g.nt = (nt_bytes >= 0 && (long)d->N * d->C * d->Ti * d->Hi * d->Wi * 4 >= nt_bytes) ? 1 : 0;
+  }
   return g;
 }
 
