@@ -779,6 +779,12 @@ def measure(args, world):
         a recording pass must not land in a timed region.  Returns the number of steps it took."""
         if dry or not engine.PLAN:
             return 0
+        if world > 1:
+            # every rank must run the SAME number of steps (each one is a set of collectives): no early exit on
+            # this rank's own plan statistics -- warm-up (4) + recording + slack for a signature that settles late
+            for n in range(8):
+                step(n, native)
+            return 8
         n = 0
         while n < limit:
             before = (engine.PLAN_STATS["recorded"], engine.PLAN_STATS["replayed"])

@@ -1518,7 +1518,8 @@ def _capture_backward(ent, dout):
 # tensor moved, re-issue the forward log; copy dout into its recorded place, re-issue the backward log, hand
 # autograd fresh aliases of the recorded gradient tensors (DDP bucket views where DDP has them).
 # COCLR_PLAN=0 switches it off (the interpreted pass); hipGraph replay (COCLR_GRAPH_QUERY) takes precedence.
-PLAN = os.environ.get("COCLR_PLAN", "1") != "0"
+PLAN = os.environ.get("COCLR_PLAN", "1") != "0" and hasattr(torch.cuda, "MemPool") and \
+    hasattr(torch.cuda, "use_mem_pool")        # (a torch without private pools: every pass stays interpreted)
 _PLAN_WARMUP = 4            # interpreted passes first: one-time allocations, DDP's bucket rebuild, slot verification
 _PLAN_MAX_SHAPES = 3        # input shapes per node that get a plan (and a pool of activations) of their own
 PLAN_STATS = {"recorded": 0, "replayed": 0, "disabled": []}
