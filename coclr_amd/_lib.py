@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
@@ -75,6 +75,8 @@ _SIGNATURES = {
     "coclr_conv3d_wgrad_workspace": [_P(ConvDesc), _P(i64)],
     "coclr_conv3d_wgrad": [_P(ConvDesc), vp, vp, vp, vp, i64, i64, i32, i32, vp],
     "coclr_conv3d_wgrad_multi": [_P(ConvDesc), vp, vp, vp, vp, i32, vp, i64, i64, i32, i32, vp],
+    "coclr_conv3d_wgrad_bn_ok": [_P(ConvDesc), _P(i32)],
+    "coclr_conv3d_wgrad_bn": [_P(ConvDesc), vp, vp, vp, i64, vp, i32, vp, vp, i64, i64, i32, i32, vp],
     "coclr_bn_finalize": [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp],
     "coclr_bn_finalize_apply": [vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp,
                                 vp, vp, i32, i64, i64, i64, i32, vp],
@@ -85,6 +87,8 @@ _SIGNATURES = {
     "coclr_bn_backward_workspace": [i32, i32, _P(i64)],
     "coclr_bn_act_backward": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64,
                               i64, i64, i64, i64, i64, i32, i32, i32, vp],
+    "coclr_bn_act_backward_coeffs": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i32,
+                                     i32, vp],
     "coclr_maxpool3d_fwd": [_P(PoolDesc), vp, vp, vp, vp, vp, i32, vp],
     "coclr_maxpool3d_bwd": [_P(PoolDesc), vp, vp, vp, i64, i64, i32, vp],
     "coclr_bn_act_backward_pooled": [_P(PoolDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64,

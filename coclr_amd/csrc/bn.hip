@@ -369,6 +369,37 @@ bn_act_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ 
   }
 }
 
+// The apply pass's coefficients WITHOUT the apply pass: coef[5][C] = A, B, D (see bn_act_bwd_apply_kernel:
+// same fold, same expressions, so a consumer that forms fmaf(A, g, fmaf(B, y, D)) itself reproduces its dy bit
+// for bit), scale, shift; plus dgamma / dbeta.  For units whose d(conv output) has one reader that can apply
+// it while it loads (coclr_conv3d_wgrad_bn).
+__global__ void __launch_bounds__(64)
+bn_bwd_coeffs_kernel(const float* __restrict__ scale, const float* __restrict__ shift,
+                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                     const double* __restrict__ sums, int groups, double count, int training, int C,
+                     float* __restrict__ coef, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int g = threadIdx.x; g < groups; g += 64) {
+    a0 += sums[((long)c * groups + g) * 2];
+    a1 += sums[((long)c * groups + g) * 2 + 1];
+  }
+  a0 = wave_sum_d(a0);
+  a1 = wave_sum_d(a1);
+  if (threadIdx.x != 0) return;
+  const double sg = a0, sgx = a1;
+  const float sc = scale[c];
+  float A = sc, B = 0.f, D = 0.f;
+  if (training) {
+    const float mg = (float)(sg / count), mgx = (float)(sgx / count);
+    B = -sc * invstd[c] * mgx;
+    D = sc * (mean[c] * invstd[c] * mgx - mg);
+  }
+  coef[c] = A; coef[C + c] = B; coef[2 * C + c] = D; coef[3 * C + c] = sc; coef[4 * C + c] = shift[c];
+  if (dgamma) dgamma[c] = (float)sgx;
+  if (dbeta) dbeta[c] = (float)sg;
+}
+
 // ---- small layers: one launch per BatchNorm unit ---------------------------------------------
 // In the last two stages of S3D a channel holds N*S = 2048..16384 values (4x4x4 / 8x8x8 maps): the
 // two-kernel forms above are launch-bound there (profiles/r01_e_layers.txt: 0.5-3.6 TB/s).  One
@@ -881,6 +912,35 @@ extern "C" int coclr_bn_act_backward(const float* dz, const float* y, const floa
                        shift, mean, invstd, sums_ws, groups, count, training, dgamma, dbeta, dy, dres,
                        N, C, (int)S, (long)dz_nstride, (long)y_nstride, (long)dy_nstride,
                        (long)z_nstride, (long)dres_nstride, relu, dres_accumulate);
+  COCLR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int coclr_bn_act_backward_coeffs(const float* dz, const float* y, const float* scale,
+                                            const float* shift, const float* mean, const float* invstd,
+                                            double* sums_ws, float* coef, float* dgamma, float* dbeta,
+                                            int N, int C, int64_t S, int64_t dz_nstride, int64_t y_nstride,
+                                            int relu, int training, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N <= 0 || C <= 0 || S <= 0 || !coef || !sums_ws) return COCLR_EINVAL;
+  const bool vec = (S % 4 == 0) && (dz_nstride % 4 == 0) && (y_nstride % 4 == 0);
+  static const long nt_bytes_c = bn_nt_bytes();          // see coclr_bn_act_apply
+  relu = relu ? 1 : 0;
+  if (nt_bytes_c >= 0 && vec && (long)N * C * S * 4 >= nt_bytes_c) relu |= 2;
+  const int groups = reduce_groups(N, (int)S);
+  dim3 rgrid(C, groups);
+  const float* noz = nullptr;
+  if (vec)
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, rgrid, dim3(256), 0, stream, dz, y, noz, scale,
+                       shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride, (long)y_nstride, 0L,
+                       relu);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<false>, rgrid, dim3(256), 0, stream, dz, y, noz, scale,
+                       shift, mean, invstd, sums_ws, N, C, (int)S, (long)dz_nstride, (long)y_nstride, 0L,
+                       relu);
+  COCLR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(C), dim3(64), 0, stream, scale, shift, mean, invstd, sums_ws,
+                     groups, (double)N * (double)S, training, C, coef, dgamma, dbeta);
   COCLR_LAUNCH_CHECK();
   return 0;
 }

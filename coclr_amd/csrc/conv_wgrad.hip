@@ -239,6 +239,12 @@ struct Wgrad2Args {
   int ntiles, S;
   int To_full;            // Winograd form: a.To counts frame PAIRS, this is the real frame count
   int xcd;                // XCD-aware (split, tile) ids, see wgrad_tile
+  // stem kernel, BNA form: `dy` is d(activation) of the BatchNorm(+ReLU) unit behind the convolution; the operand
+  // the matrix waves multiply is A[co] * g + B[co] * y + D[co], g = dz masked by (y * scale + shift > 0)
+  const float* bn_y;      // the convolution's own output
+  const float* bn_coef;   // [5][Cout]: A, B, D, scale, shift
+  long bn_y_nstride;
+  int bn_relu;
 };
 
 // (split, ci tile, co tile) of this workgroup.  Plain: the launch grid's.  XCD-aware (a.xcd): the hardware
@@ -773,7 +779,12 @@ conv_wgrad_pw_kernel(const Wgrad2Args a) {
 //   * the window sits in LDS with a row pitch == 7 (mod 32), so the 32 (kh,kw) offsets of a
 //     column block fall into distinct banks;
 //   * waves 4-7 are loaders (LDS-DMA, two stages, one barrier per 128-position box).
-template <int KH, int KW, int CIN, int PCH>
+//   * BNA: the BatchNorm backward apply pass of the unit behind the convolution happens HERE.  Nobody
+//     else reads d(conv output) of a stem (the clip needs no gradient), so the 1 GB tensor at B = 32 is
+//     neither written nor re-read: the loaders bring dz AND y rows plus one validity flag per position,
+//     the matrix waves form fmaf(A, g, fmaf(B, y, D)) -- the apply kernel's own expression, so the
+//     result is bit-identical to apply-then-multiply -- on their way from LDS to the MFMA.
+template <int KH, int KW, int CIN, int PCH, bool BNA = false>
 __global__ void __launch_bounds__(512)
 conv_wgrad_stem_kernel(const Wgrad2Args a) {
   constexpr int TAPS = KH * KW, J = CIN * TAPS, NJB = (J + 31) / 32;
@@ -781,10 +792,13 @@ conv_wgrad_stem_kernel(const Wgrad2Args a) {
   constexpr int BMt = 64;
   constexpr int LDY = BP + 1;
   constexpr int STEPS = BP / 8;          // per matrix wave: BP/4 positions, 2 per step
+  constexpr int YOFF = BMt * LDY;                          // BNA: y rows behind the dz rows
+  constexpr int VOFF = 2 * BMt * LDY;                      // BNA: BP validity flags behind them
+  constexpr int XOFF = BNA ? 2 * BMt * LDY + BP : BMt * LDY;
 
   extern __shared__ __align__(16) float smem[];
   const int planeP = a.planeP;
-  const int stage_floats = BMt * LDY + CIN * planeP;
+  const int stage_floats = XOFF + CIN * planeP;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -820,12 +834,12 @@ conv_wgrad_stem_kernel(const Wgrad2Args a) {
       const int n0 = r << a.lTN;
       const int ow0 = bw_ << lW, oh0 = bh_ << a.lTH, ot0 = bt_ << a.lTT;
       float* dYs = smem + (b & 1) * stage_floats;
-      float* Xs = dYs + BMt * LDY;
+      float* Xs = dYs + XOFF;
       // ---- dY[64][128]: rows lw, lw+4, ...; two 64-position pieces per row --------------
       {
         const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.dy + (long)n0 * a.dy_nstride), 0, 0x80000000u, 0x00020000);
-        unsigned voff[2];
+        unsigned voff[2], yoff[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int p = h * 64 + lane;
@@ -835,8 +849,12 @@ conv_wgrad_stem_kernel(const Wgrad2Args a) {
           const int tn = p >> lWHT;
           const int n = n0 + tn, ot = ot0 + tt, oh = oh0 + th, ow = ow0 + tw;
           const bool ok = n < a.N && ot < a.To && oh < a.Ho && ow < a.Wo;
-          voff[h] = ok ? (unsigned)(((long)tn * a.dy_nstride + ((long)ot * a.Ho + oh) * a.Wo + ow) * 4)
-                       : W2_OOB;
+          const long sp = ((long)ot * a.Ho + oh) * a.Wo + ow;
+          voff[h] = ok ? (unsigned)(((long)tn * a.dy_nstride + sp) * 4) : W2_OOB;
+          if (BNA) {
+            yoff[h] = ok ? (unsigned)(((long)tn * a.bn_y_nstride + sp) * 4) : W2_OOB;
+            if (lw == 0) dYs[VOFF + p] = ok ? 1.f : 0.f;
+          }
         }
         for (int row = lw; row < BMt; row += 4) {
           const int co = co0 + row;
@@ -849,6 +867,23 @@ conv_wgrad_stem_kernel(const Wgrad2Args a) {
           } else if (b < 2) {
             dYs[row * LDY + lane] = 0.f;
             dYs[row * LDY + 64 + lane] = 0.f;
+          }
+        }
+        if (BNA) {
+          const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(a.bn_y + (long)n0 * a.bn_y_nstride), 0, 0x80000000u, 0x00020000);
+          for (int row = lw; row < BMt; row += 4) {
+            const int co = co0 + row;
+            const unsigned soff = (unsigned)co * (unsigned)a.dy_cstride * 4u;
+            if (co < a.Cout) {
+#pragma unroll
+              for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, LDS_PTR(dYs + YOFF + row * LDY + h * 64), 4,
+                                                         yoff[h], soff, 0, 0);
+            } else if (b < 2) {
+              dYs[YOFF + row * LDY + lane] = 0.f;
+              dYs[YOFF + row * LDY + 64 + lane] = 0.f;
+            }
           }
         }
       }
@@ -890,8 +925,23 @@ conv_wgrad_stem_kernel(const Wgrad2Args a) {
     int j = nb * 32 + l31;
     if (j >= J) j = J - 1;                 // pad columns: computed, never stored
     const int c = j / TAPS, tap = j - c * TAPS;
-    jb[nb] = BMt * LDY + c * planeP + (tap / KW) * a.WW + (tap % KW) + half * a.sw;
+    jb[nb] = XOFF + c * planeP + (tap / KW) * a.WW + (tap % KW) + half * a.sw;
   }
+  float cA[2], cB[2], cD[2], cS[2], cF[2];
+  if (BNA) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int co = co0 + mb * 32 + l31;
+      const bool in = co < a.Cout;
+      cA[mb] = in ? a.bn_coef[co] : 0.f;
+      cB[mb] = in ? a.bn_coef[a.Cout + co] : 0.f;
+      cD[mb] = in ? a.bn_coef[2 * a.Cout + co] : 0.f;
+      cS[mb] = in ? a.bn_coef[3 * a.Cout + co] : 0.f;
+      cF[mb] = in ? a.bn_coef[4 * a.Cout + co] : 0.f;
+    }
+  }
+  const int vbase = VOFF + wave * (BP / 4) + half;
+  const bool bn_relu = BNA && a.bn_relu;
   f32x16 acc[2][NJB];
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
@@ -915,8 +965,19 @@ conv_wgrad_stem_kernel(const Wgrad2Args a) {
     float av[2][2], bv[2][NJB];
     auto fetch = [&](int s, float (&A)[2], float (&B)[NJB]) {
       const int wo = wo_of(s);
+      if (BNA) {
+        const float vm = cur[vbase + 2 * s];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) A[mb] = cur[abase[mb] + 2 * s];
+        for (int mb = 0; mb < 2; ++mb) {
+          float g = cur[abase[mb] + 2 * s];
+          const float v = cur[YOFF + abase[mb] + 2 * s];
+          if (bn_relu) g = fmaf(v, cS[mb], cF[mb]) > 0.f ? g : 0.f;
+          A[mb] = fmaf(cA[mb], g, fmaf(cB[mb], v, cD[mb] * vm));
+        }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) A[mb] = cur[abase[mb] + 2 * s];
+      }
 #pragma unroll
       for (int nb = 0; nb < NJB; ++nb) B[nb] = cur[jb[nb] + wo];
     };
@@ -1255,11 +1316,22 @@ extern "C" int coclr_conv3d_wgrad_workspace(const coclr_conv_desc* d, int64_t* e
   return 0;
 }
 
-extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x, const float* dy,
-                                        float* const* dw_list, const int32_t* row_end, int nseg,
-                                        float* workspace, int64_t w_co_stride,
-                                        int64_t w_ci_stride, int tap_base, int accumulate,
-                                        void* stream_);
+namespace {
+// BatchNorm backward apply pass folded into the weight gradient (stem kernel, BNA form)
+struct WgradBn {
+  const float* y;
+  const float* coef;
+  long y_nstride;
+  int relu;
+};
+// LDS of the stem kernel's two stages in the BNA form
+inline size_t stem_bna_lds(const WPlan& w) {
+  return 2 * ((size_t)2 * 64 * 129 + 128 + (size_t)3 * w.planeP2) * sizeof(float);
+}
+int wgrad_run(const coclr_conv_desc* d, const float* x, const float* dy, const WgradBn* bn,
+              float* const* dw_list, const int32_t* row_end, int nseg, float* workspace,
+              int64_t w_co_stride, int64_t w_ci_stride, int tap_base, int accumulate, void* stream_);
+}  // namespace
 
 extern "C" int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, const float* dy,
                                   float* dw, float* workspace, int64_t w_co_stride,
@@ -1276,6 +1348,35 @@ extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x
                                         float* workspace, int64_t w_co_stride,
                                         int64_t w_ci_stride, int tap_base, int accumulate,
                                         void* stream_) {
+  return wgrad_run(d, x, dy, nullptr, dw_list, row_end, nseg, workspace, w_co_stride, w_ci_stride, tap_base,
+                   accumulate, stream_);
+}
+
+extern "C" int coclr_conv3d_wgrad_bn_ok(const coclr_conv_desc* d, int* ok) {
+  if (!d || !ok) return COCLR_EINVAL;
+  WPlan w;
+  int rc = plan_wgrad(d, &w);
+  if (rc) return rc;
+  *ok = (w.v2 == 9 && stem_bna_lds(w) <= (size_t)160 * 1024) ? 1 : 0;
+  return 0;
+}
+
+extern "C" int coclr_conv3d_wgrad_bn(const coclr_conv_desc* d, const float* x, const float* dz, const float* y,
+                                     int64_t y_nstride, const float* coef, int relu, float* dw,
+                                     float* workspace, int64_t w_co_stride, int64_t w_ci_stride, int tap_base,
+                                     int accumulate, void* stream_) {
+  if (!d || !y || !coef) return COCLR_EINVAL;
+  float* one[1] = {dw};
+  const int32_t end[1] = {d->Cout};
+  const WgradBn bn = {y, coef, (long)y_nstride, relu ? 1 : 0};
+  return wgrad_run(d, x, dz, &bn, one, end, 1, workspace, w_co_stride, w_ci_stride, tap_base, accumulate,
+                   stream_);
+}
+
+namespace {
+int wgrad_run(const coclr_conv_desc* d, const float* x, const float* dy, const WgradBn* bn,
+              float* const* dw_list, const int32_t* row_end, int nseg, float* workspace,
+              int64_t w_co_stride, int64_t w_ci_stride, int tap_base, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !dw_list || !row_end || nseg < 1 || nseg > 4) return COCLR_EINVAL;
   WgradDst dst;
@@ -1289,6 +1390,7 @@ extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x
   WPlan w;
   int rc = plan_wgrad(d, &w);
   if (rc) return rc;
+  if (bn && !(w.v2 == 9 && stem_bna_lds(w) <= (size_t)160 * 1024)) return COCLR_EINVAL;   // see _bn_ok
   const int taps = d->kt * d->kh * d->kw;
   int S_used;
   if (w.v2) {
@@ -1310,6 +1412,8 @@ extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x
     a.ntiles = p.ntiles; a.S = w.S2;
     a.To_full = d->To;
     a.xcd = wgrad_tile_fastest(d);
+    a.bn_y = bn ? bn->y : nullptr; a.bn_coef = bn ? bn->coef : nullptr;
+    a.bn_y_nstride = bn ? bn->y_nstride : 0; a.bn_relu = bn ? bn->relu : 0;
     if (w.v2 == 6) a.dy_cstride = d->To * p.Ho * p.Wo;     // p.To counts pairs there
     const int pch = cdiv(p.plane, 64);
     const bool pw = w.pw && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0;
@@ -1345,10 +1449,17 @@ extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x
       case 7: rc = pch <= 2 ? launch_wgrad2<1, 3, 3, 1, 1, 2, false, 4, true>(a, w, stream)
                             : launch_wgrad2<1, 3, 3, 1, 1, 3, false, 4, true>(a, w, stream); break;
       case 9: {
-        auto kern = conv_wgrad_stem_kernel<7, 7, 3, 20>;
-        static std::atomic<uint64_t> attr_done{0};
-        COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
-        hipLaunchKernelGGL(kern, dim3(w.S2, 1, w.mt2), dim3(512), w.lds2, stream, a);
+        if (bn) {
+          auto kern = conv_wgrad_stem_kernel<7, 7, 3, 20, true>;
+          static std::atomic<uint64_t> attr_done{0};
+          COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+          hipLaunchKernelGGL(kern, dim3(w.S2, 1, w.mt2), dim3(512), stem_bna_lds(w), stream, a);
+        } else {
+          auto kern = conv_wgrad_stem_kernel<7, 7, 3, 20>;
+          static std::atomic<uint64_t> attr_done{0};
+          COCLR_RETURN_IF(ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done));
+          hipLaunchKernelGGL(kern, dim3(w.S2, 1, w.mt2), dim3(512), w.lds2, stream, a);
+        }
         COCLR_LAUNCH_CHECK();
         rc = 0;
         break;
@@ -1393,3 +1504,4 @@ extern "C" int coclr_conv3d_wgrad_multi(const coclr_conv_desc* d, const float* x
   COCLR_LAUNCH_CHECK();
   return 0;
 }
+}  // namespace

@@ -1,2 +1,2 @@
 #include "../../include/coclr_hip.h"
-extern "C" int coclr_abi_version(void) { return 19; }
+extern "C" int coclr_abi_version(void) { return 20; }

@@ -963,11 +963,20 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
             run.bn_src[id(out.base)] = (y, scale, shift, mean, invstd, relu)
 
         def backward(run):
-            dy = torch.empty_like(y)
             dgb = (run.grad_out(bn.weight), run.grad_out(bn.bias))
             sums = run.empty(ops.bn_backward_workspace(N, Cout), dtype=torch.float64)
             pooled = run.pooled.pop(id(out.base), None)
-            if pooled is not None:
+            # Nobody needs this unit's data gradient (the stem over the clip) and its weight-gradient kernel can
+            # apply BatchNorm's backward while it loads: d(conv output) -- 1 GB at B = 32 -- is never written.
+            fused = WGRAD_BN and pooled is None and residual is None and not x_needs and not sliced and \
+                w.requires_grad and id(out.base) not in run.bn_parts and geoms[0].wgrad_bn_ok()
+            dy = None if fused else torch.empty_like(y)
+            if fused:
+                coef = run.empty(5, Cout)
+                dz = run.grad_of(out)
+                ops.bn_act_backward_coeffs(dz, y, scale, shift, mean, invstd, sums, coef, dgb[0], dgb[1], relu,
+                                           training)
+            elif pooled is not None:
                 # the unit's only reader was a max-pool that applied BN+ReLU itself: its backward left
                 # (geometry, d(pool output), arg-max) here and d(activation) is never materialised
                 ops.bn_act_backward_pooled(pooled[0], pooled[1], pooled[2], y, scale, shift, mean,
@@ -991,7 +1000,14 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
                 run.add_param_grad(bn.weight, dgb[0])
             if bn.bias.requires_grad:
                 run.add_param_grad(bn.bias, dgb[1])
-            if w.requires_grad:
+            if fused:
+                with torch.cuda.stream(run.side_stream(dz, y, coef, xv)):
+                    dw = run.grad_out(w)
+                    kk = w.shape[2] * w.shape[3] * w.shape[4]
+                    ops.conv_wgrad_bn(geoms[0], xv, dz, y, coef, relu, dw, run.empty(geoms[0].wgrad_workspace()),
+                                      Cin * kk, kk)
+                run.add_param_grad(w, dw)
+            elif w.requires_grad:
                 with torch.cuda.stream(run.side_stream(dy, xv)):
                     dw = run.grad_out(w)
                     kk = w.shape[2] * w.shape[3] * w.shape[4]
@@ -1037,6 +1053,8 @@ def conv_bn_act_gen(run, x, conv, bn, relu=True, out=None, residual=None, n_inde
 
 
 LAZY_APPLY = os.environ.get("COCLR_LAZY_APPLY", "1") != "0"
+# BatchNorm's backward apply pass inside the weight gradient that is its only reader (the (1,7,7) stem)
+WGRAD_BN = os.environ.get("COCLR_WGRAD_BN", "1") != "0"
 # BatchNorm + ReLU of a unit applied by the CONVOLUTION that consumes it (gradient-free passes, kernels that can)
 IN_AFFINE = os.environ.get("COCLR_IN_AFFINE", "1") != "0"
 

@@ -260,6 +260,17 @@ class ConvGeom:
             v = self._cache["bwd_sums_ok"] = bool(out.value)
         return v
 
+    def wgrad_bn_ok(self):
+        """Is there a weight-gradient kernel that applies the BatchNorm backward of the unit behind this
+        convolution while it loads (conv_wgrad_bn)?"""
+        v = self._cache.get("wgrad_bn_ok")
+        if v is None:
+            out = C.c_int32(0)
+            _lib.check(_L().coclr_conv3d_wgrad_bn_ok(C.byref(self.desc), C.byref(out)),
+                       "conv3d_wgrad_bn_ok", self)
+            v = self._cache["wgrad_bn_ok"] = bool(out.value)
+        return v
+
     def wgrad_workspace(self):
         v = self._cache.get("wgws")
         if v is None:
@@ -438,6 +449,18 @@ def conv_wgrad(geom, x, dy, dw, workspace, co_stride, ci_stride, tap_base, accum
         int(accumulate), _stream()), "conv3d_wgrad", geom)
 
 
+def conv_wgrad_bn(geom, x, dz, y, coef, relu, dw, workspace, co_stride, ci_stride, tap_base=0,
+                  accumulate=False):
+    """conv_wgrad over dy = BatchNorm(+ReLU) backward of (dz, y) formed on the fly (coef from
+    bn_act_backward_coeffs); geom.wgrad_bn_ok() geometries only."""
+    d = _desc(geom)
+    d.x_nstride = _chk5(x, "x")
+    d.y_nstride = _chk5(dz, "dz")
+    _lib.check(_L().coclr_conv3d_wgrad_bn(
+        C.byref(d), _p(x), _p(dz), _p(y), _chk5(y, "y"), _p(coef), int(relu), _p(dw), _p(workspace),
+        co_stride, ci_stride, tap_base, int(accumulate), _stream()), "conv3d_wgrad_bn", geom)
+
+
 # ---- batch norm ------------------------------------------------------------------
 
 def bn_finalize(stats, C_, ntiles, count, gamma, beta, running_mean, running_var, nbt, momentum,
@@ -561,6 +584,20 @@ def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dga
         _chk5(dz, "dz"), _chk5(y, "y"), _chk5(dy, "dy"), _chk5(z, "z") if z is not None else 0,
         _chk5(dres, "dres") if dres is not None else 0, int(relu), int(training),
         int(dres_accumulate), _stream()), "bn_act_backward")
+
+
+def bn_act_backward_coeffs(dz, y, scale, shift, mean, invstd, sums_ws, coef, dgamma, dbeta, relu, training):
+    """The reduction pass of bn_act_backward and coef[5][C] (A, B, D, scale, shift) of its apply pass, which
+    the reader of dy runs itself (conv_wgrad_bn)."""
+    N, C_, T, H, W = y.shape
+    if sums_ws.numel() < 2 * C_ * N:
+        raise ValueError("coclr_amd: bn_act_backward workspace too small")
+    if coef.numel() < 5 * C_:
+        raise ValueError("coclr_amd: bn_act_backward_coeffs needs 5 x C coefficients")
+    _lib.check(_L().coclr_bn_act_backward_coeffs(
+        _p(dz), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(sums_ws, torch.float64), _p(coef),
+        _p(dgamma), _p(dbeta), N, C_, T * H * W, _chk5(dz, "dz"), _chk5(y, "y"), int(relu), int(training),
+        _stream()), "bn_act_backward_coeffs")
 
 
 # ---- pooling ---------------------------------------------------------------------

@@ -29,7 +29,7 @@ PROBE = None
 # host-side queries (no launch, results cached by their callers): never part of a plan
 _QUERIES = frozenset((
     "coclr_abi_version", "coclr_conv_packed_size", "coclr_conv_pack_describe", "coclr_conv3d_ntiles",
-    "coclr_conv3d_bwd_sums_ok", "coclr_conv3d_wgrad_workspace", "coclr_bn_backward_workspace",
+    "coclr_conv3d_bwd_sums_ok", "coclr_conv3d_wgrad_bn_ok", "coclr_conv3d_wgrad_workspace", "coclr_bn_backward_workspace",
     "coclr_bn_act_backward_pooled_fits", "coclr_gemm_workspace", "coclr_colstats_workspace"))
 
 _CARG = type(C.byref(C.c_int()))

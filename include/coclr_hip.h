@@ -179,6 +179,21 @@ int coclr_conv3d_wgrad(const coclr_conv_desc* d, const float* x, const float* dy
                        float* workspace, int64_t w_co_stride, int64_t w_ci_stride, int tap_base,
                        int accumulate, void* stream);
 
+/* The weight gradient of a convolution whose BatchNorm(+ReLU) backward apply pass has NOT run: `dz` is
+ * d(activation) of the unit behind the convolution (backbone/s3dg.py:24-28: conv -> bn -> relu), `y` the
+ * convolution's own output, coef[5][Cout] what coclr_bn_act_backward_coeffs left.  The kernel forms
+ *   dy = A[co] * g + B[co] * y + D[co],   g = relu ? (y * scale[co] + shift[co] > 0 ? dz : 0) : dz
+ * -- the expression of coclr_bn_act_backward's second pass, bit for bit -- between LDS and the matrix
+ * pipe, so d(conv output) is never written or re-read.  For units whose data gradient nobody needs (the
+ * (1,7,7) stem over the clip: 1 GB per pass at B = 32); coclr_conv3d_wgrad_bn_ok says whether the geometry
+ * has such a kernel, COCLR_EINVAL otherwise.  Replaces the native_batch_norm_backward +
+ * convolution_backward pair autograd runs for backbone/s3dg.py:145 (Conv_1a.conv1 / bn1). */
+int coclr_conv3d_wgrad_bn_ok(const coclr_conv_desc* d, int* ok);
+int coclr_conv3d_wgrad_bn(const coclr_conv_desc* d, const float* x, const float* dz, const float* y,
+                          int64_t y_nstride, const float* coef, int relu, float* dw, float* workspace,
+                          int64_t w_co_stride, int64_t w_ci_stride, int tap_base, int accumulate,
+                          void* stream);
+
 /* The same gradient delivered to up to four destinations: output-channel rows
  * [row_end[i-1], row_end[i]) go to dw_list[i] (row index local to the destination;
  * row_end[nseg-1] == d->Cout).  For convolutions that stand for several parameters at once --
@@ -239,6 +254,17 @@ int coclr_bn_act_backward(const float* dz, const float* y, const float* z, const
                           int N, int C, int64_t S, int64_t dz_nstride, int64_t y_nstride,
                           int64_t dy_nstride, int64_t z_nstride, int64_t dres_nstride, int relu,
                           int training, int dres_accumulate, void* stream);
+
+/* The first pass of the above plus the coefficients of its second, for a unit whose d(conv output) is
+ * applied by its one reader (coclr_conv3d_wgrad_bn): coef[5][C] = A, B, D, scale, shift with
+ * dy = A*g + B*y + D (training: A = scale, B = -scale*invstd*mean(g*xhat),
+ * D = scale*(mean*invstd*mean(g*xhat) - mean(g)); frozen statistics: dy = scale*g); dgamma / dbeta as
+ * above.  Two launches, no pass that writes dy. */
+int coclr_bn_act_backward_coeffs(const float* dz, const float* y, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, double* sums_ws, float* coef,
+                                 float* dgamma, float* dbeta, int N, int C, int64_t S,
+                                 int64_t dz_nstride, int64_t y_nstride, int relu, int training,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Pooling (backbone/s3dg.py:105,151,162,173,190; resnet_2d3d.py:141;        */

@@ -276,6 +276,37 @@ def bn_act_backward(dz, y, z, scale, shift, mean, invstd, sums_ws, dy, dres, dga
         dy.copy_(_b(scale) * g)
 
 
+def bn_act_backward_coeffs(dz, y, scale, shift, mean, invstd, sums_ws, coef, dgamma, dbeta, relu, training):
+    g = dz * ((y * _b(scale) + _b(shift)) > 0) if relu else dz
+    xhat = (y - _b(mean)) * _b(invstd)
+    sg = g.double().sum((0, 2, 3, 4))
+    sgx = (g.double() * xhat.double()).sum((0, 2, 3, 4))
+    if dgamma is not None:
+        dgamma.copy_(sgx.float())
+    if dbeta is not None:
+        dbeta.copy_(sg.float())
+    c = coef.view(5, -1)
+    c[0].copy_(scale)
+    c[3].copy_(scale)
+    c[4].copy_(shift)
+    if training:
+        cnt = y.numel() / y.shape[1]
+        mg, mgx = (sg / cnt).float(), (sgx / cnt).float()
+        c[1].copy_(-scale * invstd * mgx)
+        c[2].copy_(scale * (mean * invstd * mgx - mg))
+    else:
+        c[1].zero_()
+        c[2].zero_()
+
+
+def conv_wgrad_bn(geom, x, dz, y, coef, relu, dw, workspace, co_stride, ci_stride, tap_base=0,
+                  accumulate=False):
+    c = coef.view(5, -1)
+    g = dz * ((y * _b(c[3]) + _b(c[4])) > 0) if relu else dz
+    conv_wgrad(geom, x, _b(c[0]) * g + _b(c[1]) * y + _b(c[2]), dw, workspace, co_stride, ci_stride, tap_base,
+               accumulate)
+
+
 def maxpool_fwd(geom, x, y, indices=None, in_scale=None, in_shift=None, in_relu=False):
     if in_scale is not None:
         x = x * _b(in_scale) + _b(in_shift)

@@ -107,6 +107,80 @@ def test_conv_dgrad_wgrad(case):
     close(dw, w.grad, what="wgrad")
 
 
+@pytest.mark.parametrize("relu,training", [(True, True), (False, True), (True, False)],
+                         ids=["bn_relu_train", "bn_train", "bn_relu_frozen"])
+@pytest.mark.parametrize("N,dims", [(2, (8, 32, 32)), (3, (5, 30, 26)), (3, (11, 70, 66)), (5, (8, 64, 64))],
+                         ids=["even", "ragged", "ragged_streaming", "streaming"])
+def test_stem_weight_gradient_applies_batchnorm_backward(N, dims, relu, training):
+    """coclr_conv3d_wgrad_bn (the (1,7,7) stem, backbone/s3dg.py:145): the weight gradient formed straight from
+    d(activation) and the conv output, BatchNorm's backward applied between LDS and the matrix pipe -- against
+    autograd on the CPU, and BIT-IDENTICAL to the two-pass form (bn_act_backward then conv_wgrad) wherever that
+    form runs the same reduction (channels of more than ops.SMALL_CHANNEL values: the streaming kernels)."""
+    from coclr_amd import ops
+    torch.manual_seed(11)
+    Cin, Cout, k, s, p = 3, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)
+    x = torch.randn(N, Cin, *dims)
+    w = (torch.randn(Cout, Cin, *k) * 0.05).requires_grad_(True)
+    gamma = (torch.rand(Cout) + 0.5).requires_grad_(True)
+    beta = (torch.randn(Cout) * 0.3).requires_grad_(True)
+    rm, rv = torch.randn(Cout) * 0.1, torch.rand(Cout) + 0.5
+    y = F.conv3d(x, w, None, s, p)
+    z = F.batch_norm(y, rm.clone(), rv.clone(), gamma, beta, training, 0.1, 1e-5)
+    if relu:
+        z = torch.relu(z)
+    dz = torch.randn_like(z)
+    z.backward(dz)
+
+    g = ops.ConvGeom(N, Cin, Cout, dims, k, s, p)
+    assert g.wgrad_bn_ok()
+    yd, xd = dev(y.detach()), dev(x)
+    if training:
+        mean = y.detach().double().mean((0, 2, 3, 4))
+        var = y.detach().double().var((0, 2, 3, 4), unbiased=False)
+    else:
+        mean, var = rm.double(), rv.double()
+    invstd = (var + 1e-5).rsqrt()
+    scale = gamma.detach().double() * invstd
+    shift = beta.detach().double() - mean * scale
+    small = dev(torch.stack([mean, invstd, scale, shift]).float())
+    # d(activation) lives in a channel slice of a wider tensor (sample stride != C * S)
+    dzw = torch.zeros(N, Cout + 5, *g.odim, device="cuda")
+    dzd = dzw[:, 2:2 + Cout]
+    dzd.copy_(dev(dz))
+    nws = ops.bn_backward_workspace(N, Cout)
+    kk = k[0] * k[1] * k[2]
+    # two passes: dy written, then read
+    dy = torch.empty_like(yd)
+    dgb = torch.empty(2, Cout, device="cuda")
+    ops.bn_act_backward(dzd, yd, None, small[2], small[3], small[0], small[1],
+                        torch.full((nws,), float("nan"), dtype=torch.float64, device="cuda"), dy, None, dgb[0],
+                        dgb[1], relu, training)
+    dw2 = torch.empty(Cout, Cin, *k, device="cuda")
+    ops.conv_wgrad(g, xd, dy, dw2, torch.empty(g.wgrad_workspace(), device="cuda"), Cin * kk, kk, 0)
+    # one: coefficients, then the weight gradient applies them
+    coef = torch.full((5, Cout), float("nan"), device="cuda")
+    dgb1 = torch.empty(2, Cout, device="cuda")
+    ops.bn_act_backward_coeffs(dzd, yd, small[2], small[3], small[0], small[1],
+                               torch.full((nws,), float("nan"), dtype=torch.float64, device="cuda"), coef,
+                               dgb1[0], dgb1[1], relu, training)
+    dw1 = torch.full((Cout, Cin, *k), float("nan"), device="cuda")
+    ops.conv_wgrad_bn(g, xd, dzd, yd, coef, relu, dw1, torch.empty(g.wgrad_workspace(), device="cuda"),
+                      Cin * kk, kk)
+    torch.cuda.synchronize()
+    if N * g.odim[0] * g.odim[1] * g.odim[2] > ops.SMALL_CHANNEL:
+        assert torch.equal(dgb1, dgb)
+        assert torch.equal(dw1, dw2)
+    else:
+        close(dgb1, dgb, rtol=1e-5, what="sums, one-launch form")
+        close(dw1, dw2, rtol=1e-5, what="wgrad, one-launch form")
+    close(dw1, w.grad, rtol=5e-4, what="stem wgrad through BatchNorm")
+    close(dgb1[0], gamma.grad, rtol=5e-4, what="dgamma")
+    close(dgb1[1], beta.grad, rtol=5e-4, what="dbeta")
+    # not a stem: no such kernel, and the call says so
+    g2 = ops.ConvGeom(2, 64, 64, (4, 16, 16), (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    assert not g2.wgrad_bn_ok()
+
+
 @pytest.mark.parametrize("wino", [True, False], ids=["winograd_phases", "direct_phases"])
 @pytest.mark.parametrize("T", [8, 9, 32, 34, 37])
 def test_conv_dgrad_phase_decomposition(T, wino, monkeypatch):
