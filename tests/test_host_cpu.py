@@ -864,6 +864,47 @@ def test_bn_backward_sums_formed_by_the_writing_data_gradient(fake, monkeypatch)
         assert (ga[k] - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-8, k
 
 
+def test_stem_backward_takes_the_short_form(fake, monkeypatch):
+    """engine: the unit whose data gradient nobody needs (Conv_1a.conv1 over the clip) skips BatchNorm's backward
+    apply pass -- reduction + coefficients, then the weight gradient that applies them (ops.conv_wgrad_bn) -- and
+    every other unit keeps the two-pass form; COCLR_WGRAD_BN=0 switches it off.  Host logic on the CPU double,
+    against the same model without it; the kernel is held bit-identical to the two-pass form on the GPU
+    (tests/test_gpu_kernels.py::test_stem_weight_gradient_applies_batchnorm_backward)."""
+    from coclr_amd import engine, ops
+    from coclr_amd.backbone import s3dg
+    seen = {"short": 0, "coeffs": 0}
+    real_w, real_c = ops.conv_wgrad_bn, ops.bn_act_backward_coeffs
+
+    def spy_w(geom, *a, **k):
+        seen["short"] += 1
+        assert geom.k == (1, 7, 7) and geom.Cin == 3
+        return real_w(geom, *a, **k)
+
+    def spy_c(*a, **k):
+        seen["coeffs"] += 1
+        return real_c(*a, **k)
+
+    monkeypatch.setattr(ops, "conv_wgrad_bn", spy_w)
+    monkeypatch.setattr(ops, "bn_act_backward_coeffs", spy_c)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 3, 8, 32, 32, generator=g)
+    results = []
+    for on in (True, False):
+        monkeypatch.setattr(engine, "WGRAD_BN", on)
+        torch.manual_seed(0)
+        m = s3dg.S3D(input_channel=3).train()
+        seen["short"] = seen["coeffs"] = 0
+        out = m(x)
+        out.square().mean().backward()
+        results.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, dict(seen)))
+    (oa, ga, sa), (ob, gb, sb) = results
+    assert sa == {"short": 1, "coeffs": 1} and sb == {"short": 0, "coeffs": 0}, (sa, sb)
+    assert torch.equal(oa, ob)
+    for k in ga:
+        ref = gb[k]
+        assert (ga[k] - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-8, k
+
+
 def test_launch_plan_mechanics():
     """coclr_amd/plan.py without a GPU: a log of (C function, frozen arguments) and Python callables is re-issued in
     order; byref'd descriptors are COPIED at recording time (the shared geometry descriptors are rewritten by later
