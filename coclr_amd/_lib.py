@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoclr_hip.so")
+LIB_PATH = os.environ.get("COCLR_LIB_PATH") or os.path.join(_HERE, "libcoclr_hip.so")
 ABI_VERSION = 20
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
