@@ -22,6 +22,18 @@ def fake(monkeypatch):
     fake_backend.install(monkeypatch)
 
 
+@pytest.fixture(autouse=True)
+def _leave_a_core_free():
+    """The scripts run in-process next to their own helper threads (DDP's reducer, the autograd thread, the
+    reference's plotter thread): with one ATen intra-op thread per core every OpenMP barrier spins until the
+    scheduler lets the displaced thread back in, and these four tests took anything between 1 and 22 minutes on
+    the 8-core container.  Half the cores for ATen keeps them at their fast end."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(n, 4)))
+    yield
+    torch.set_num_threads(n)
+
+
 def _compare(gold, rec, two_stream):
     n = len(gold["outputs"])
     assert len(rec["outputs"]) == len(rec["losses"]) == n
